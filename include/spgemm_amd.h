@@ -1,0 +1,183 @@
+/*
+ * spgemm_amd.h - C ABI of the MI355X (gfx950) SpGEMM engine.
+ *
+ * This is the drop-in boundary for the multiply path of sven-weber/spgemm
+ * (the `mults` operators and the partition / bitmap / exchange helpers around
+ * them).  Plain pointers and sizes only; every function returns an int status
+ * (SPGEMM_OK == 0) and never throws; spgemm_last_error() gives the message of
+ * the last failure on the calling thread.  One context per caller thread and
+ * per GPU.  There is no CPU fallback: every entry point that computes needs a
+ * HIP device and fails with SPGEMM_ERR_HIP when none is usable.
+ *
+ * Data layout (device, structure of arrays):
+ *   row_ptr  uint64_t[rows + 1]   (the reference's midx_t row_ptr is 32 bit,
+ *                                  include/matrix.hpp:9; C can exceed 2^32 here)
+ *   col_idx  uint32_t[nnz]        (reference midx_t)
+ *   val      double[nnz]
+ * Rows of an OUTPUT matrix are sorted by column and hold no entry whose
+ * accumulated value is exactly 0.0 (the reference erases such entries,
+ * include/matrix_impl.hpp:90-93).  Rows of an INPUT matrix may be in any
+ * order; products are accumulated in the storage order of the A row, which is
+ * the order the reference's loops use (src/mults/drop_parallel.cpp:46-57).
+ */
+#ifndef SPGEMM_AMD_H
+#define SPGEMM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPGEMM_OK 0
+#define SPGEMM_ERR_INVALID 1     /* bad argument / malformed matrix */
+#define SPGEMM_ERR_HIP 2         /* a HIP runtime call failed (or no device) */
+#define SPGEMM_ERR_NOMEM 3       /* device or host allocation failed */
+#define SPGEMM_ERR_STATE 4       /* call made in the wrong state */
+#define SPGEMM_ERR_UNSUPPORTED 5 /* size beyond what this build supports */
+
+typedef struct spgemm_ctx spgemm_ctx;
+typedef struct spgemm_mat spgemm_mat;
+
+/* reference include/partition.hpp:10-15 (Partition) */
+typedef struct spgemm_partition {
+  uint32_t start_row;
+  uint32_t end_row;
+  uint32_t start_col;
+  uint32_t end_col;
+} spgemm_partition;
+
+/* Per-multiply figures; times are device times between HIP events recorded on
+ * the context's stream.  Phase names extend the reference's measure points
+ * (include/measure.hpp:16-30: "mult", "bitmaps", ...). */
+typedef struct spgemm_stats {
+  uint64_t rows_a;
+  uint64_t nnz_a;
+  uint64_t nnz_b;
+  uint64_t nprod;          /* sum over A entries (i,k) of nnz(B[k,:]); flops = 2*nprod */
+  uint64_t nnz_structural; /* distinct (i,j) hit by a product */
+  uint64_t nnz_c;          /* after dropping exact zeros */
+  uint64_t bytes_algorithmic; /* 12*(nnzA+nprod+nnzC) + 4*(rowsA+1) + 8*(rowsC+1) */
+  uint64_t temp_bytes;     /* scratch held by the context after this multiply */
+  uint32_t rows_window;    /* rows accumulated through an LDS bitmap window */
+  uint32_t rows_hash;      /* rows accumulated through an LDS hash table */
+  uint32_t rows_global;    /* rows accumulated in global-memory scratch */
+  uint32_t rows_empty;
+  float ms_analyze;        /* B row info + A row analysis + binning */
+  float ms_symbolic;
+  float ms_scan;
+  float ms_numeric;
+  float ms_compact;        /* only when an exact zero had to be dropped */
+  float ms_total;          /* first to last event of the multiply */
+} spgemm_stats;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int spgemm_version(void);
+const char *spgemm_last_error(void);
+int spgemm_device_count(int *count);
+
+/* ---- context: the per-rank state the reference keeps in a mults::MatrixMultiplication
+ *      object (include/mults.hpp:17-33) ----------------------------------------------------- */
+int spgemm_create(int device, spgemm_ctx **ctx);
+int spgemm_destroy(spgemm_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. the framework's current stream). NULL restores the
+ * context's own stream. */
+int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
+int spgemm_synchronize(spgemm_ctx *ctx);
+/* Tunables, by name (e.g. "window_max_span", "lanes_scale"); unknown names are an error. */
+int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value);
+
+/* ---- matrices: replace matrix::ManagedCSRMatrix / CSRMatrix
+ *      (include/matrix_impl.hpp:230-384) --------------------------------------------------- */
+/* Copy a host CSR to the device. The caller keeps ownership of the host arrays. */
+int spgemm_mat_from_host(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz,
+                         const uint64_t *row_ptr, const uint32_t *col_idx, const double *val,
+                         spgemm_mat **out);
+/* Wrap device arrays without copying; they must outlive the handle. validate != 0 runs a
+ * device pass that checks row_ptr monotonicity and col_idx < cols. */
+int spgemm_mat_wrap_device(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz,
+                           const uint64_t *d_row_ptr, const uint32_t *d_col_idx,
+                           const double *d_val, int validate, spgemm_mat **out);
+int spgemm_mat_info(const spgemm_mat *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz);
+int spgemm_mat_device_ptrs(const spgemm_mat *m, const uint64_t **d_row_ptr,
+                           const uint32_t **d_col_idx, const double **d_val);
+int spgemm_mat_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *row_ptr,
+                       uint32_t *col_idx, double *val);
+int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m);
+
+/* ---- the multiply: replaces reset() + the local multiply inside gemm()
+ *      (src/mults/outer.cpp:61-73, drop.cpp:76-88, drop_parallel.cpp:43-59,
+ *       drop_at_once_parallel.cpp:120-131, baseline.cpp:48-71; accumulator
+ *       include/matrix_impl.hpp:81-95; CSR build :275-315) --------------------------------- */
+int spgemm_multiply(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, spgemm_mat **C);
+/* Staged form for callers that own the output buffers (device pointers).
+ * symbolic: fills d_row_ptr[rows_a + 1] with the structural row pointer and returns its last
+ *           entry.  numeric: must follow symbolic on the same (A, B) with no other multiply in
+ *           between; writes col_idx/val (capacity nnz_structural) and, when exact zeros were
+ *           dropped, compacts in place and rewrites d_row_ptr; returns the final nnz. */
+int spgemm_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B,
+                    uint64_t *d_row_ptr, uint64_t *nnz_structural);
+int spgemm_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B,
+                   uint64_t *d_row_ptr, uint32_t *d_col_idx, double *d_val, uint64_t *nnz_final);
+int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out);
+
+/* ---- section bitmap: replaces bitmap::compute_bitmap (src/bitmap.cpp:12-40).
+ *      bit s = min(col / (A.cols / n_sections), n_sections - 1); words_out is a HOST array of
+ *      ceil(n_sections / 64) words.  Fails with SPGEMM_ERR_INVALID when A.cols / n_sections
+ *      == 0 (the reference asserts). --------------------------------------------------------- */
+int spgemm_section_bitmap(spgemm_ctx *ctx, const spgemm_mat *A, uint32_t n_sections,
+                          uint64_t *words_out);
+
+/* ---- partitions: replace parts::baseline::partition / balanced_partition
+ *      (src/parts/baseline.cpp:10-42, :44-86).  Host-side integer work. ------------------- */
+int spgemm_partition_naive(uint32_t height, uint32_t width, int n_parts, spgemm_partition *out);
+/* Rows are cut where the running sum of row_weight exceeds sum/n_parts (the reference weighs
+ * by nnz of the rows of C_sparsity; any per-row weight can be given, e.g. spgemm_row_nprod). */
+int spgemm_partition_balanced(const uint64_t *row_weight, uint32_t height, uint32_t width,
+                              int n_parts, spgemm_partition *out);
+/* Per-row product counts of A*B (HOST array of A.rows entries): a balance weight that does not
+ * need the answer's pattern. */
+int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B,
+                     uint64_t *row_nprod_out);
+
+/* ---- shuffle: replaces partition::shuffle (src/partition.cpp:15-37), but seeded so runs are
+ *      reproducible. perm_out[i] = original index placed at position i. ------------------- */
+int spgemm_shuffle_random(uint32_t n, uint64_t seed, uint32_t *perm_out);
+
+/* ---- operand selection: what the reference's loader does with keep_rows / keep_cols
+ *      (include/matrix_impl.hpp:163-221, src/main.cpp:213-217), on the device.
+ *      keep_rows (HOST, may be NULL = all rows in order): output row r is input row
+ *      keep_rows[r].  col_new_id (HOST, may be NULL = unchanged): an entry in column c moves to
+ *      column col_new_id[c]; entries whose new id is 0xFFFFFFFF are removed.  Output rows are
+ *      sorted by new column id when sort_rows != 0, else keep the input order. -------------- */
+int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uint32_t *keep_rows,
+                      uint64_t n_keep_rows, const uint32_t *col_new_id, uint64_t new_cols,
+                      int sort_rows, spgemm_mat **out);
+
+/* ---- B exchange helpers: replace BlockedCSRMatrix::filter + the receive-side rebuild
+ *      (include/matrix_impl.hpp:507-534, :480-485) for a B that is cut into n_sections row
+ *      sections of height rows/n_sections (last one takes the remainder, :628-639).
+ *
+ *  section_nnz:  HOST array of n_sections entries = stored entries per row section of M.
+ *  pack:         gathers the row lengths / col_idx / val of the sections whose bit is set in
+ *                bitmap_words (HOST) into caller device buffers, sections in ascending order;
+ *                returns rows and entries written.
+ *  assemble:     builds, on the receiving side, the row pointer of a B that has all `rows` rows
+ *                where only the sections set in bitmap_words are present (others empty), from
+ *                the concatenated row lengths of the present sections; col_idx/val of that B
+ *                are simply the concatenated payloads. --------------------------------------- */
+int spgemm_section_nnz(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sections,
+                       uint64_t first_row, uint64_t total_rows, uint64_t *nnz_out);
+int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sections,
+                         uint64_t first_row, uint64_t total_rows, const uint64_t *bitmap_words,
+                         uint32_t *d_row_len_out, uint32_t *d_col_idx_out, double *d_val_out,
+                         uint64_t *rows_out, uint64_t *nnz_out);
+int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
+                            const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
+                            uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPGEMM_AMD_H */

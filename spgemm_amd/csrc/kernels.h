@@ -1,0 +1,978 @@
+// Device kernels of the gfx950 SpGEMM engine (row-wise Gustavson, C = A * B, fp64).
+//
+// Execution model used throughout: 64-lane wavefronts; a "group" is G consecutive lanes
+// (G in {8,16,32,64}) inside one wavefront.  LDS operations of one wavefront execute in issue
+// order, so lanes of a wavefront hand data to each other through LDS with a compiler-only
+// fence (lds_fence) and no s_barrier.
+//
+// Ordering rule that makes the result bit-identical to the reference's CPU loop
+// (src/mults/drop_parallel.cpp:46-57, accumulator include/matrix_impl.hpp:81-95): every output
+// row is owned by ONE group; the group walks the A row's entries sequentially in storage order
+// (the k order of the CPU loop) and, for one k, its lanes take different entries of B row k,
+// which have distinct columns.  Every (i,j) therefore receives its additions in the same order
+// as on the CPU, products and sums are rounded separately (no fused multiply-add), and no
+// two lanes of one instruction ever add to the same accumulator.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sg {
+
+constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_NONE = 255u; // row needs no kernel (no products)
+
+// ---- bin keys ------------------------------------------------------------------------------
+// symbolic:  [0,24)  window, key = span_tier*4 + gsel, span <= 2048 << span_tier
+//            [24,40) hash,   key = 24 + tier*4 + gsel, nprod <= 64 << (2*tier)
+//            [40,44) global, key = 40 + gsel
+// numeric:   [0,96)   window, key = (span_tier*4 + cap_tier)*4 + gsel, nnz <= 128 << (2*cap_tier)
+//            [96,112) hash,   key = 96 + cap_tier*4 + gsel,             nnz <= 64 << (2*cap_tier)
+//            112      global
+constexpr int SYM_WIN0 = 0, SYM_HASH0 = 24, SYM_GLOBAL0 = 40, SYM_NBINS = 44;
+constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = 112, NUM_NBINS = 113;
+constexpr int MAX_BINS = 128;
+
+struct ClassParams {
+  uint32_t win_max_span;   // window path allowed up to this column span (<= 65536)
+  uint32_t win_ratio;      // ... and only if span <= win_ratio * nprod
+  uint32_t hash_max_nprod; // LDS hash symbolic up to this many products (<= 4096)
+  uint32_t g_thresh0, g_thresh1, g_thresh2; // mean B-row length thresholds for 8/16/32 lanes
+};
+
+__host__ __device__ inline uint32_t ceil_log2_u32(uint32_t x) {
+  uint32_t l = 0;
+  while ((1u << l) < x && l < 31) ++l;
+  return l;
+}
+
+__host__ __device__ inline uint32_t gsel_of(uint64_t nprod, uint32_t len_a, const ClassParams &p) {
+  uint32_t avg = len_a ? (uint32_t)((nprod + len_a - 1) / len_a) : 0;
+  return avg <= p.g_thresh0 ? 0u : avg <= p.g_thresh1 ? 1u : avg <= p.g_thresh2 ? 2u : 3u;
+}
+
+__host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, uint32_t len_a,
+                                               const ClassParams &p) {
+  if (nprod == 0) return KEY_NONE;
+  uint32_t g = gsel_of(nprod, len_a, p);
+  if (span <= p.win_max_span && (uint64_t)span <= (uint64_t)p.win_ratio * nprod) {
+    uint32_t t = ceil_log2_u32(span < 2048u ? 2048u : span) - 11u;
+    return SYM_WIN0 + t * 4 + g;
+  }
+  if (nprod <= p.hash_max_nprod) {
+    uint32_t t = nprod <= 64 ? 0u : nprod <= 256 ? 1u : nprod <= 1024 ? 2u : 3u;
+    return SYM_HASH0 + t * 4 + g;
+  }
+  return SYM_GLOBAL0 + g;
+}
+
+__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz) {
+  if (nnz == 0) return KEY_NONE;
+  uint32_t g = sym_key & 3u;
+  if (sym_key < (uint32_t)SYM_HASH0) {
+    uint32_t st = sym_key >> 2;
+    if (nnz <= 8192u) {
+      uint32_t ct = nnz <= 128 ? 0u : nnz <= 512 ? 1u : nnz <= 2048 ? 2u : 3u;
+      return NUM_WIN0 + (st * 4 + ct) * 4 + g;
+    }
+    return NUM_GLOBAL;
+  }
+  if (nnz <= 4096u) {
+    uint32_t ct = nnz <= 64 ? 0u : nnz <= 256 ? 1u : nnz <= 1024 ? 2u : 3u;
+    return NUM_HASH0 + ct * 4 + g;
+  }
+  return NUM_GLOBAL;
+}
+
+// ---- small device helpers ------------------------------------------------------------------
+__device__ __forceinline__ void lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  asm volatile("" ::: "memory");
+}
+
+template <int W> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v) {
+  const int l = threadIdx.x & (W - 1);
+#pragma unroll
+  for (int d = 1; d < W; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, W);
+    if (l >= d) v += t;
+  }
+  return v;
+}
+template <int W> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, W);
+  return v;
+}
+template <int W> __device__ __forceinline__ uint64_t group_sum64(uint64_t v) {
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, W);
+  return v;
+}
+template <int W> __device__ __forceinline__ uint32_t group_min(uint32_t v) {
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d, W));
+  return v;
+}
+template <int W> __device__ __forceinline__ uint32_t group_max(uint32_t v) {
+#pragma unroll
+  for (int d = W / 2; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, W));
+  return v;
+}
+
+// Workgroups b and b+8 share an XCD (round-robin dispatch).  Map the hardware block id to a
+// logical id so that every XCD works on one contiguous range of rows: neighbouring rows read
+// the same B rows, which then stay in that XCD's L2.  Bijective for every nb.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+  uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, j = b >> 3;
+  uint32_t start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + j;
+}
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t c, uint32_t log2s) {
+  return (c * 0x9E3779B1u) >> (32u - log2s);
+}
+
+// LDS fp64 accumulate: ds_add_f64 (plain IEEE add of an already rounded product).
+__device__ __forceinline__ void lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// ---- B row info: {min col, max col, length} of every B row ---------------------------------
+// 8 lanes per row; rows may be unsorted.
+__global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
+                                                   const uint32_t *__restrict__ b_col,
+                                                   uint4 *__restrict__ info) {
+  constexpr int G = 8;
+  uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  uint64_t b0 = 0, b1 = 0;
+  if (row < rows) {
+    b0 = b_ptr[row];
+    b1 = b_ptr[row + 1];
+  }
+  for (uint64_t j = b0 + lg; j < b1; j += G) {
+    uint32_t c = b_col[j];
+    mn = min(mn, c);
+    mx = max(mx, c);
+  }
+  mn = group_min<G>(mn);
+  mx = group_max<G>(mx);
+  if (row < rows && lg == 0) {
+    uint64_t len = b1 - b0;
+    info[row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, 0u);
+  }
+}
+
+// ---- A row analysis --------------------------------------------------------------------------
+// Per A row: nprod = sum of B row lengths, [cmin, cmax] = hull of the B rows' column ranges,
+// the symbolic bin key and the upper bound `ub` on the row's distinct columns.
+struct AnalyzeOut {
+  uint32_t *r_cmin;
+  uint32_t *r_cmax;
+  uint32_t *r_ub;
+  uint8_t *r_key;
+  uint64_t *r_nprod;       // optional (may be null)
+  uint64_t *total_nprod;   // single counter
+  uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
+  uint32_t *long_count;
+};
+
+__device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32_t mn, uint32_t mx,
+                                               uint32_t len_a, const AnalyzeOut &o,
+                                               const ClassParams &cp) {
+  uint32_t span = np ? (mx - mn + 1u) : 0u;
+  uint32_t key = sym_key_of(np, span, len_a, cp);
+  uint64_t ub = np;
+  if (key != KEY_NONE && (key < (uint32_t)SYM_HASH0 || key >= (uint32_t)SYM_GLOBAL0))
+    ub = np < span ? np : span;
+  o.r_cmin[row] = mn;
+  o.r_cmax[row] = mx;
+  o.r_ub[row] = (uint32_t)ub;
+  o.r_key[row] = (uint8_t)key;
+  if (o.r_nprod) o.r_nprod[row] = np;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_analyze(uint32_t rows_a, const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
+              const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp, uint32_t long_len) {
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint64_t np = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  uint64_t a0 = 0, a1 = 0;
+  bool is_long = false;
+  if (row < rows_a) {
+    a0 = a_ptr[row];
+    a1 = a_ptr[row + 1];
+    is_long = (a1 - a0) > long_len;
+  }
+  if (!is_long) {
+    for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
+      uint4 bi = b_info[a_col[ka]];
+      if (bi.z) {
+        np += bi.z;
+        mn = min(mn, bi.x);
+        mx = max(mx, bi.y);
+      }
+    }
+  }
+  np = group_sum64<G>(np);
+  mn = group_min<G>(mn);
+  mx = group_max<G>(mx);
+  uint64_t contrib = 0;
+  if (row < rows_a && lg == 0) {
+    if (is_long) {
+      uint32_t p = atomicAdd(o.long_count, 1u);
+      o.long_rows[p] = row;
+    } else {
+      analyze_finish(row, np, mn, mx, (uint32_t)(a1 - a0), o, cp);
+      contrib = np;
+    }
+  }
+  // one atomic per wavefront for the product total
+  contrib = group_sum64<64>(contrib);
+  if ((threadIdx.x & 63) == 0 && contrib) atomicAdd((unsigned long long *)o.total_nprod, (unsigned long long)contrib);
+}
+
+// One 256-thread workgroup per long A row.
+__global__ void __launch_bounds__(256)
+    k_analyze_long(const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
+                   const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp) {
+  __shared__ uint64_t s_np[4];
+  __shared__ uint32_t s_mn[4], s_mx[4];
+  uint32_t nlong = *o.long_count;
+  for (uint32_t idx = blockIdx.x; idx < nlong; idx += gridDim.x) {
+    uint32_t row = o.long_rows[idx];
+    uint64_t a0 = a_ptr[row], a1 = a_ptr[row + 1];
+    uint64_t np = 0;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (uint64_t ka = a0 + threadIdx.x; ka < a1; ka += blockDim.x) {
+      uint4 bi = b_info[a_col[ka]];
+      if (bi.z) {
+        np += bi.z;
+        mn = min(mn, bi.x);
+        mx = max(mx, bi.y);
+      }
+    }
+    np = group_sum64<64>(np);
+    mn = group_min<64>(mn);
+    mx = group_max<64>(mx);
+    uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      s_np[w] = np;
+      s_mn[w] = mn;
+      s_mx[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      np = s_np[0] + s_np[1] + s_np[2] + s_np[3];
+      mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+      mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+      analyze_finish(row, np, mn, mx, (uint32_t)(a1 - a0), o, cp);
+      if (np) atomicAdd((unsigned long long *)o.total_nprod, (unsigned long long)np);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- exclusive scan (uint32 in, uint64 out), three launches ----------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8; // per thread -> 2048 per workgroup
+
+__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t *s_wave /*>=4*/, uint64_t *total) {
+  // inclusive scan inside the wavefront
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = __shfl_up(x, d, 64);
+    if (lane >= d) x += t;
+  }
+  if (lane == 63) s_wave[w] = x;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) {
+    if (i < w) base += s_wave[i];
+    tot += s_wave[i];
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+    k_scan_partials(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ partial) {
+  __shared__ uint64_t s_wave[4];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + (uint64_t)i * SCAN_BLOCK + threadIdx.x;
+    if (idx < n) s += in[idx];
+  }
+  uint64_t tot;
+  block_excl_scan64(s, s_wave, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the partials in place; total -> partial[nparts]
+__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *partial, uint32_t nparts) {
+  __shared__ uint64_t s_wave[16];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nparts; base += 1024) {
+    uint32_t idx = base + threadIdx.x;
+    uint64_t v = idx < nparts ? partial[idx] : 0;
+    uint64_t tot;
+    uint64_t ex = block_excl_scan64(v, s_wave, &tot);
+    uint64_t carry = s_carry;
+    if (idx < nparts) partial[idx] = ex + carry;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[nparts] = s_carry;
+}
+
+// out[i] = exclusive prefix; out[n] = total.  Items are laid out thread-contiguous here so the
+// per-thread prefix is a running sum.
+__global__ void __launch_bounds__(SCAN_BLOCK)
+    k_scan_final(const uint32_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ partial,
+                 uint64_t *__restrict__ out, uint32_t nparts) {
+  __shared__ uint64_t s_wave[4];
+  __shared__ uint32_t s_items[SCAN_BLOCK * SCAN_ITEMS];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t l = i * SCAN_BLOCK + threadIdx.x;
+    uint64_t idx = base + l;
+    s_items[l] = idx < n ? in[idx] : 0u;
+  }
+  __syncthreads();
+  uint32_t v[SCAN_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = s_items[threadIdx.x * SCAN_ITEMS + i];
+    s += v[i];
+  }
+  uint64_t ex = block_excl_scan64(s, s_wave, nullptr) + partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + (uint64_t)threadIdx.x * SCAN_ITEMS + i;
+    if (idx < n) out[idx] = ex;
+    ex += v[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nparts];
+}
+
+// ---- stable partition of rows by an 8-bit key ---------------------------------------------------
+constexpr int PART_BLOCK = 256;
+constexpr int PART_ROUNDS = 4; // 1024 rows per workgroup
+
+__global__ void __launch_bounds__(PART_BLOCK)
+    k_part_hist(const uint8_t *__restrict__ key, uint32_t n, uint32_t nbins, uint32_t nblocks,
+                uint32_t *__restrict__ blk_hist /* [nbins][nblocks] */) {
+  __shared__ uint32_t s_h[MAX_BINS];
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) s_h[b] = 0;
+  __syncthreads();
+  uint32_t base = blockIdx.x * PART_BLOCK * PART_ROUNDS;
+  for (int r = 0; r < PART_ROUNDS; ++r) {
+    uint32_t i = base + r * PART_BLOCK + threadIdx.x;
+    if (i < n) {
+      uint32_t k = key[i];
+      if (k < nbins) atomicAdd(&s_h[k], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) blk_hist[(size_t)b * nblocks + blockIdx.x] = s_h[b];
+}
+
+// blk_off = exclusive scan of blk_hist (bin-major), so bin b starts at blk_off[b*nblocks].
+__global__ void __launch_bounds__(PART_BLOCK)
+    k_part_scatter(const uint8_t *__restrict__ key, uint32_t n, uint32_t nbins, uint32_t nblocks,
+                   const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ rows_out) {
+  __shared__ uint32_t s_base[MAX_BINS];
+  __shared__ uint32_t s_wcnt[4][MAX_BINS];
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK)
+    s_base[b] = (uint32_t)blk_off[(size_t)b * nblocks + blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t base = blockIdx.x * PART_BLOCK * PART_ROUNDS;
+  for (int r = 0; r < PART_ROUNDS; ++r) {
+    for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) {
+      s_wcnt[0][b] = 0; s_wcnt[1][b] = 0; s_wcnt[2][b] = 0; s_wcnt[3][b] = 0;
+    }
+    __syncthreads();
+    uint32_t i = base + r * PART_BLOCK + threadIdx.x;
+    uint32_t k = i < n ? key[i] : KEY_NONE;
+    bool valid = k < nbins;
+    uint32_t rank = 0;
+    unsigned long long left = __ballot(valid);
+    while (left) {
+      int leader = __ffsll((long long)left) - 1;
+      uint32_t kb = __shfl(k, leader, 64);
+      unsigned long long m = __ballot(valid && k == kb);
+      if (valid && k == kb) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if ((int)lane == leader) s_wcnt[w][kb] = __popcll(m);
+      left &= ~m;
+    }
+    __syncthreads();
+    if (valid) {
+      uint32_t off = s_base[k] + rank;
+      for (uint32_t ww = 0; ww < w; ++ww) off += s_wcnt[ww][k];
+      rows_out[off] = i;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK)
+      s_base[b] += s_wcnt[0][b] + s_wcnt[1][b] + s_wcnt[2][b] + s_wcnt[3][b];
+    __syncthreads();
+  }
+}
+
+// bin_off[b] = start of bin b in rows_out (b = 0..nbins), read from the scanned histogram.
+__global__ void k_part_binoff(const uint64_t *__restrict__ blk_off, uint32_t nbins, uint32_t nblocks,
+                              uint64_t *__restrict__ bin_off) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nbins) bin_off[b] = blk_off[(size_t)b * nblocks];
+}
+
+// ---- common per-row context ------------------------------------------------------------------
+struct Csr {
+  const uint64_t *__restrict__ ptr;
+  const uint32_t *__restrict__ col;
+  const double *__restrict__ val;
+};
+
+struct RowMeta {
+  const uint32_t *__restrict__ cmin;
+  const uint32_t *__restrict__ cmax;
+  const uint8_t *__restrict__ sym_key;
+  const uint64_t *__restrict__ t_off; // offset of the row's slot in temp_cols
+  uint32_t *__restrict__ temp_cols;   // sorted structural columns per row (written by symbolic)
+  uint32_t *__restrict__ nnz;         // structural nnz per row
+  uint8_t *__restrict__ num_key;      // numeric bin key per row
+};
+
+// ---- symbolic, window path: one wavefront per row, LPK lanes per A entry -----------------------
+// LDS per wavefront: `words` uint32 bitmap words covering columns [cmin & ~31, cmax].
+// Order-free (bit OR), so the A entries are spread over 64/LPK sub-groups.
+template <int LPK>
+__global__ void __launch_bounds__(256)
+    k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+                 uint32_t words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (idx >= nrows) return;
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem) + (size_t)w * words;
+  const uint32_t row = rows[idx];
+  const uint32_t base = m.cmin[row] & ~31u;
+  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
+  for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
+  lds_fence();
+  constexpr uint32_t NSG = 64 / LPK;
+  const uint32_t sg = lane / LPK, sl = lane % LPK;
+  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+  for (uint64_t ka = a0 + sg; ka < a1; ka += NSG) {
+    uint32_t k = A.col[ka];
+    uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+    for (uint64_t jb = b0 + sl; jb < b1; jb += LPK) {
+      uint32_t c = B.col[jb] - base;
+      atomicOr(&bm[c >> 5], 1u << (c & 31u));
+    }
+  }
+  lds_fence();
+  // enumerate set bits in ascending order -> sorted structural columns
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t bits = wi < nw ? bm[wi] : 0u;
+    uint32_t pc = __popc(bits);
+    uint32_t incl = group_incl_scan<64>(pc);
+    uint32_t pos = carry + incl - pc;
+    uint32_t cbase = base + (wi << 5);
+    while (bits) {
+      uint32_t b = __ffs(bits) - 1;
+      out[pos++] = cbase + b;
+      bits &= bits - 1u;
+    }
+    carry += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) {
+    m.nnz[row] = carry;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry);
+  }
+}
+
+// ---- symbolic, hash path: one wavefront per row ----------------------------------------------
+// LDS per wavefront: keys[S] | cnt[S/2] | tk[S/2]  (uint32 each) = 8*S bytes, S = 1 << log2s.
+// S >= 2 * nprod, so the table is at most half full.  Sorting is a bucket rank sort: a monotone
+// map of the column into S/2 buckets, counting sort into bucket order, then each key finds its
+// rank among the (few) keys of its bucket.
+template <int LPK>
+__global__ void __launch_bounds__(256)
+    k_sym_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+               uint32_t log2s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (idx >= nrows) return;
+  const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem) + (size_t)w * (2u * S);
+  uint32_t *cnt = keys + S;
+  uint32_t *tk = cnt + NB;
+  const uint32_t row = rows[idx];
+  for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
+  for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
+  lds_fence();
+  constexpr uint32_t NSG = 64 / LPK;
+  const uint32_t sg = lane / LPK, sl = lane % LPK;
+  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+  uint32_t mine = 0;
+  for (uint64_t ka = a0 + sg; ka < a1; ka += NSG) {
+    uint32_t k = A.col[ka];
+    uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+    for (uint64_t jb = b0 + sl; jb < b1; jb += LPK) {
+      uint32_t c = B.col[jb];
+      uint32_t h = hash_slot(c, log2s);
+      for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+        uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+        if (old == EMPTY_KEY) { ++mine; break; }
+        if (old == c) break;
+        h = (h + 1u) & mask;
+      }
+    }
+  }
+  lds_fence();
+  const uint32_t n = group_sum<64>(mine);
+  const uint32_t cmin = m.cmin[row];
+  const float scale = (float)NB / (float)(m.cmax[row] - cmin + 1u);
+  // pass A: bucket counts
+  for (uint32_t s = lane; s < S; s += 64) {
+    uint32_t key = keys[s];
+    if (key != EMPTY_KEY) {
+      uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+      atomicAdd(&cnt[b], 1u);
+    }
+  }
+  lds_fence();
+  // exclusive scan of cnt
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < NB; r0 += 64) {
+    uint32_t v = cnt[r0 + lane]; // NB is a multiple of 64
+    uint32_t incl = group_incl_scan<64>(v);
+    cnt[r0 + lane] = carry + incl - v;
+    carry += __shfl(incl, 63, 64);
+  }
+  lds_fence();
+  // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
+  for (uint32_t s = lane; s < S; s += 64) {
+    uint32_t key = keys[s];
+    if (key != EMPTY_KEY) {
+      uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+      uint32_t p = atomicAdd(&cnt[b], 1u);
+      tk[p] = key;
+    }
+  }
+  lds_fence();
+  // pass C: rank inside the bucket, write sorted
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t key = tk[p];
+    uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+    uint32_t start = b ? cnt[b - 1] : 0u, end = cnt[b];
+    uint32_t rank = start;
+    for (uint32_t q = start; q < end; ++q) rank += (tk[q] < key) ? 1u : 0u;
+    out[rank] = key;
+  }
+  if (lane == 0) {
+    m.nnz[row] = n;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
+  }
+}
+
+// ---- symbolic, global path: one 256-thread workgroup per row, bitmap in global scratch ---------
+// scratch: per workgroup `words_total` uint32 words, all zero on entry and on exit.
+__global__ void __launch_bounds__(256)
+    k_sym_global(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+                 uint32_t *__restrict__ scratch, uint64_t words_total) {
+  __shared__ uint64_t s_wave[4];
+  __shared__ uint32_t s_carry;
+  uint32_t *bm = scratch + (size_t)blockIdx.x * words_total;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t idx = blockIdx.x; idx < nrows; idx += gridDim.x) {
+    const uint32_t row = rows[idx];
+    const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
+    const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+    for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
+      uint32_t k = A.col[ka];
+      uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+      for (uint64_t jb = b0 + lane; jb < b1; jb += 64) {
+        uint32_t c = B.col[jb];
+        atomicOr(&bm[c >> 5], 1u << (c & 31u));
+      }
+    }
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    uint32_t *out = m.temp_cols + m.t_off[row];
+    for (uint32_t r0 = w0; r0 <= w1; r0 += 256) {
+      uint32_t wi = r0 + threadIdx.x;
+      uint32_t bits = 0;
+      if (wi <= w1) bits = atomicExch(&bm[wi], 0u); // read through L2 and clear
+      uint32_t pc = __popc(bits);
+      uint64_t tot;
+      uint32_t ex = (uint32_t)block_excl_scan64(pc, s_wave, &tot);
+      uint32_t pos = s_carry + ex;
+      uint32_t cbase = wi << 5;
+      while (bits) {
+        uint32_t b = __ffs(bits) - 1;
+        out[pos++] = cbase + b;
+        bits &= bits - 1u;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_carry += (uint32_t)tot;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      uint32_t n = s_carry;
+      m.nnz[row] = n;
+      m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- numeric -----------------------------------------------------------------------------------
+struct NumOut {
+  const uint64_t *__restrict__ c_ptr;
+  uint32_t *__restrict__ c_col;
+  double *__restrict__ c_val;
+  unsigned long long *zero_count; // entries whose accumulated value is exactly 0.0
+};
+
+// Walk the products of `row` in the CPU order and call acc(col, product).
+// The group preloads G A entries (column, value, B row bounds) at a time, then visits them one
+// by one; for one A entry the G lanes take consecutive entries of the B row.
+template <int G, class F>
+__device__ __forceinline__ void for_each_product(const Csr &A, const Csr &B, uint32_t row, uint32_t lg, F acc) {
+  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+  for (uint64_t ab = a0; ab < a1; ab += G) {
+    uint64_t ka = ab + lg;
+    uint32_t k = 0;
+    double av = 0.0;
+    uint64_t b0 = 0, b1 = 0;
+    if (ka < a1) {
+      k = A.col[ka];
+      av = A.val[ka];
+      b0 = B.ptr[k];
+      b1 = B.ptr[k + 1];
+    }
+    const uint32_t cnt = (uint32_t)min((uint64_t)G, a1 - ab);
+    for (uint32_t t = 0; t < cnt; ++t) {
+      const double avt = __shfl(av, t, G);
+      const uint64_t b0t = __shfl(b0, t, G), b1t = __shfl(b1, t, G);
+      for (uint64_t jb = b0t + lg; jb < b1t; jb += G) {
+        uint32_t c = B.col[jb];
+        double p = __dmul_rn(avt, B.val[jb]);
+        acc(c, p);
+      }
+    }
+  }
+}
+
+// numeric, window path: G lanes per row.
+// LDS per group: bmp[words] of {lo: bitmap word, hi: number of set bits before the word}
+//                | vals[cap] doubles.
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_num_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                 uint32_t words, uint32_t cap, uint32_t gpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lg = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
+  if (gid >= gpb || idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (size_t)cap * 8u;
+  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + gid * region);
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  double *vals = reinterpret_cast<double *>(bmp + words);
+  const uint32_t row = rows[idx];
+  const uint32_t base = m.cmin[row] & ~31u;
+  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
+  const uint32_t n = m.nnz[row];
+  const uint64_t off = o.c_ptr[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[row];
+  for (uint32_t i = lg; i < nw; i += G) bmp[i] = 0ull;
+  for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
+  lds_fence();
+  for (uint32_t p = lg; p < n; p += G) {
+    uint32_t c = tin[p];
+    o.c_col[off + p] = c;
+    uint32_t cc = c - base;
+    atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += G) {
+    uint32_t wi = r0 + lg;
+    uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<G>(pc);
+    if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
+    carry += __shfl(incl, G - 1, G);
+  }
+  lds_fence();
+  for_each_product<G>(A, B, row, lg, [&](uint32_t c, double p) {
+    uint32_t cc = c - base;
+    uint64_t e = bmp[cc >> 5];
+    uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+    if (pos < n) lds_add_f64(&vals[pos], p);
+  });
+  lds_fence();
+  uint32_t nz = 0;
+  for (uint32_t p = lg; p < n; p += G) {
+    double v = vals[p];
+    o.c_val[off + p] = v;
+    nz += (v == 0.0) ? 1u : 0u;
+  }
+  nz = group_sum<G>(nz);
+  if (lg == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, hash path: G lanes per row.
+// LDS per group: keys[S] uint32 | pos[S] uint16 | vals[S/2] double = 10*S bytes; nnz <= S/2.
+// The sorted structural columns are inserted first (slot -> output position), so the
+// accumulate loop only probes (no compare-and-swap) and the output needs no sort.
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_num_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+               uint32_t log2s, uint32_t gpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lg = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
+  if (gid >= gpb || idx >= nrows) return;
+  const uint32_t S = 1u << log2s, mask = S - 1u;
+  const size_t region = (size_t)S * 10u;
+  unsigned char *reg = smem + gid * region;
+  double *vals = reinterpret_cast<double *>(reg);                 // S/2 doubles = 4*S bytes
+  uint32_t *keys = reinterpret_cast<uint32_t *>(reg + 4u * S);    // S uint32
+  uint16_t *pos = reinterpret_cast<uint16_t *>(reg + 8u * S);     // S uint16
+  const uint32_t row = rows[idx];
+  const uint32_t n = m.nnz[row];
+  const uint64_t off = o.c_ptr[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[row];
+  for (uint32_t i = lg; i < S; i += G) keys[i] = EMPTY_KEY;
+  for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
+  lds_fence();
+  for (uint32_t p = lg; p < n; p += G) {
+    uint32_t c = tin[p];
+    o.c_col[off + p] = c;
+    uint32_t h = hash_slot(c, log2s);
+    uint32_t it = 0;
+    while (atomicCAS(&keys[h], EMPTY_KEY, c) != EMPTY_KEY && it < S) { h = (h + 1u) & mask; ++it; }
+    if (it < S) pos[h] = (uint16_t)p;
+  }
+  lds_fence();
+  for_each_product<G>(A, B, row, lg, [&](uint32_t c, double p) {
+    uint32_t h = hash_slot(c, log2s);
+    uint32_t it = 0;
+    while (keys[h] != c && it < S) { h = (h + 1u) & mask; ++it; }
+    if (it < S) lds_add_f64(&vals[pos[h]], p);
+  });
+  lds_fence();
+  uint32_t nz = 0;
+  for (uint32_t p = lg; p < n; p += G) {
+    double v = vals[p];
+    o.c_val[off + p] = v;
+    nz += (v == 0.0) ? 1u : 0u;
+  }
+  nz = group_sum<G>(nz);
+  if (lg == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, global path: ONE wavefront per row (the k order must be kept), accumulating straight
+// into the row's slice of c_val through L2 atomics.  scratch: per workgroup `words_total`
+// {bitmap word, prefix} pairs, all zero on entry and on exit.
+__global__ void __launch_bounds__(64)
+    k_num_global(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                 unsigned long long *__restrict__ scratch, uint64_t words_total) {
+  unsigned long long *bmp = scratch + (size_t)blockIdx.x * words_total;
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t idx = blockIdx.x; idx < nrows; idx += gridDim.x) {
+    const uint32_t row = rows[idx];
+    const uint32_t n = m.nnz[row];
+    const uint64_t off = o.c_ptr[row];
+    const uint32_t *tin = m.temp_cols + m.t_off[row];
+    const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
+    for (uint32_t p = lane; p < n; p += 64) {
+      uint32_t c = tin[p];
+      o.c_col[off + p] = c;
+      __hip_atomic_store(&o.c_val[off + p], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(&bmp32[(size_t)(c >> 5) * 2u], 1u << (c & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    uint32_t carry = 0;
+    for (uint32_t r0 = w0; r0 <= w1; r0 += 64) {
+      uint32_t wi = r0 + lane;
+      uint32_t bits = 0;
+      if (wi <= w1) bits = __hip_atomic_load(&bmp32[(size_t)wi * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t pc = __popc(bits);
+      uint32_t incl = group_incl_scan<64>(pc);
+      if (wi <= w1 && bits)
+        __hip_atomic_store(&bmp32[(size_t)wi * 2u + 1u], carry + incl - pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      carry += __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    for_each_product<64>(A, B, row, lane, [&](uint32_t c, double p) {
+      unsigned long long e = __hip_atomic_load(&bmp[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (c & 31u)) - 1u));
+      if (pos < n) unsafeAtomicAdd(&o.c_val[off + pos], p);
+    });
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    uint32_t nz = 0;
+    for (uint32_t p = lane; p < n; p += 64) {
+      double v = __hip_atomic_load(&o.c_val[off + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nz += (v == 0.0) ? 1u : 0u;
+      uint32_t c = tin[p];
+      __hip_atomic_store(&bmp[c >> 5], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    nz = group_sum<64>(nz);
+    if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
+}
+
+// ---- dropping exact zeros (rare) ----------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_count_nonzero(uint32_t rows, const uint64_t *__restrict__ c_ptr, const double *__restrict__ c_val,
+                    uint32_t *__restrict__ keep) {
+  constexpr int G = 8;
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t cnt = 0;
+  if (row < rows)
+    for (uint64_t j = c_ptr[row] + lg; j < c_ptr[row + 1]; j += G) cnt += (c_val[j] != 0.0) ? 1u : 0u;
+  cnt = group_sum<G>(cnt);
+  if (row < rows && lg == 0) keep[row] = cnt;
+}
+
+// one wavefront per row, order-preserving
+__global__ void __launch_bounds__(256)
+    k_compact_rows(uint32_t rows, const uint64_t *__restrict__ old_ptr, const uint32_t *__restrict__ old_col,
+                   const double *__restrict__ old_val, const uint64_t *__restrict__ new_ptr,
+                   uint32_t *__restrict__ new_col, double *__restrict__ new_val) {
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  uint64_t j0 = old_ptr[row], j1 = old_ptr[row + 1];
+  uint64_t out = new_ptr[row];
+  for (uint64_t jb = j0; jb < j1; jb += 64) {
+    uint64_t j = jb + lane;
+    double v = j < j1 ? old_val[j] : 0.0;
+    bool keepit = j < j1 && v != 0.0;
+    unsigned long long mball = __ballot(keepit);
+    if (keepit) {
+      uint64_t p = out + __popcll(mball & ((1ull << lane) - 1ull));
+      new_col[p] = old_col[j];
+      new_val[p] = v;
+    }
+    out += __popcll(mball);
+  }
+}
+
+// ---- section bitmap (reference src/bitmap.cpp:12-40) ---------------------------------------------
+constexpr uint32_t MAX_SECTIONS = 4096;
+__global__ void __launch_bounds__(256)
+    k_section_bitmap(uint64_t nnz, const uint32_t *__restrict__ a_col, uint32_t section_width,
+                     uint32_t n_sections, uint32_t *__restrict__ words /* ceil(n/32), pre-zeroed */) {
+  __shared__ uint32_t s_bits[MAX_SECTIONS / 32];
+  const uint32_t nwords = (n_sections + 31u) >> 5;
+  for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) s_bits[i] = 0u;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t s = min(a_col[i] / section_width, n_sections - 1u);
+    uint32_t bit = 1u << (s & 31u);
+    if (!(s_bits[s >> 5] & bit)) atomicOr(&s_bits[s >> 5], bit);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x)
+    if (s_bits[i]) atomicOr(&words[i], s_bits[i]);
+}
+
+// ---- validation ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_validate(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t *__restrict__ ptr,
+               const uint32_t *__restrict__ col, uint32_t *__restrict__ bad) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = i; r < rows; r += stride)
+    if (ptr[r] > ptr[r + 1] || ptr[r + 1] > nnz) atomicOr(bad, 1u);
+  if (i == 0 && (ptr[0] != 0 || ptr[rows] != nnz)) atomicOr(bad, 2u);
+  for (uint64_t j = i; j < nnz; j += stride)
+    if ((uint64_t)col[j] >= cols) atomicOr(bad, 4u);
+}
+
+// ---- operand selection (keep_rows / column relabel) ------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_select_count(uint64_t n_out, const uint32_t *__restrict__ keep_rows, const uint64_t *__restrict__ ptr,
+                   const uint32_t *__restrict__ col, const uint32_t *__restrict__ col_new,
+                   uint32_t *__restrict__ out_len) {
+  constexpr int G = 8;
+  uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t cnt = 0;
+  if (r < n_out) {
+    uint64_t src = keep_rows ? keep_rows[r] : r;
+    uint64_t j0 = ptr[src], j1 = ptr[src + 1];
+    if (col_new) {
+      for (uint64_t j = j0 + lg; j < j1; j += G) cnt += (col_new[col[j]] != 0xFFFFFFFFu) ? 1u : 0u;
+    } else if (lg == 0) {
+      cnt = (uint32_t)(j1 - j0);
+    }
+  }
+  cnt = group_sum<G>(cnt);
+  if (r < n_out && lg == 0) out_len[r] = cnt;
+}
+
+// one wavefront per output row, order-preserving copy with relabel
+__global__ void __launch_bounds__(256)
+    k_select_copy(uint64_t n_out, const uint32_t *__restrict__ keep_rows, const uint64_t *__restrict__ ptr,
+                  const uint32_t *__restrict__ col, const double *__restrict__ val,
+                  const uint32_t *__restrict__ col_new, const uint64_t *__restrict__ out_ptr,
+                  uint32_t *__restrict__ out_col, double *__restrict__ out_val) {
+  uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (r >= n_out) return;
+  uint64_t src = keep_rows ? keep_rows[r] : r;
+  uint64_t j0 = ptr[src], j1 = ptr[src + 1];
+  uint64_t out = out_ptr[r];
+  for (uint64_t jb = j0; jb < j1; jb += 64) {
+    uint64_t j = jb + lane;
+    uint32_t c = 0xFFFFFFFFu;
+    if (j < j1) {
+      c = col[j];
+      if (col_new) c = col_new[c];
+    }
+    bool keepit = j < j1 && c != 0xFFFFFFFFu;
+    unsigned long long mball = __ballot(keepit);
+    if (keepit) {
+      uint64_t p = out + __popcll(mball & ((1ull << lane) - 1ull));
+      out_col[p] = c;
+      out_val[p] = val[j];
+    }
+    out += __popcll(mball);
+  }
+}
+
+// ---- B exchange helpers ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_row_len(uint64_t rows, const uint64_t *__restrict__ ptr, uint32_t *__restrict__ len) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) len[r] = (uint32_t)(ptr[r + 1] - ptr[r]);
+}
+
+} // namespace sg

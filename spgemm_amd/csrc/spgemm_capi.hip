@@ -1,0 +1,1198 @@
+// C-ABI of the gfx950 SpGEMM engine (include/spgemm_amd.h): contexts, device matrices, the
+// symbolic -> scan -> numeric pipeline, and the partition / bitmap / exchange helpers.
+#include "../../include/spgemm_amd.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace sg;
+
+// ---- errors -------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(e_ == hipErrorOutOfMemory ? SPGEMM_ERR_NOMEM : SPGEMM_ERR_HIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+  } while (0)
+
+#define TRY(expr)                                                                                   \
+  do {                                                                                              \
+    int rc_ = (expr);                                                                               \
+    if (rc_ != SPGEMM_OK) return rc_;                                                               \
+  } while (0)
+
+// ---- objects ------------------------------------------------------------------------------------
+struct spgemm_mat {
+  uint64_t rows = 0, cols = 0, nnz = 0;
+  uint64_t *d_ptr = nullptr;
+  uint32_t *d_col = nullptr;
+  double *d_val = nullptr;
+  bool owns = false;
+  int device = 0;
+  uint4 *d_rowinfo = nullptr; // {min col, max col, length} per row, built on first use as B
+  size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0;
+};
+
+struct Block {
+  void *p;
+  size_t bytes;
+};
+
+struct Growable {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct spgemm_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  ClassParams cp;
+  size_t lds_budget = 64 * 1024; // LDS bytes per workgroup aimed for (>= 2 workgroups per CU)
+  uint32_t long_len = 2048;      // A rows longer than this are analysed by a whole workgroup
+  uint32_t global_blocks_sym = 512;
+  uint32_t global_blocks_num = 2048;
+  Growable arena;     // per-multiply row arrays
+  Growable temp_cols; // sorted structural columns (symbolic -> numeric)
+  Growable gscratch;  // bitmap scratch of the global path (kept zero between uses)
+  size_t gscratch_zeroed = 0;
+  void *h_pinned = nullptr; // small host staging buffer
+  uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
+  std::vector<Block> pool;  // freed output buffers, reused by later multiplies
+  size_t pool_bytes = 0;
+  spgemm_stats stats;
+  // state carried from spgemm_symbolic to spgemm_numeric
+  struct Plan {
+    bool valid = false;
+    const spgemm_mat *A = nullptr, *B = nullptr;
+    uint32_t *r_cmin = nullptr, *r_cmax = nullptr, *r_nnz = nullptr;
+    uint8_t *r_key = nullptr, *r_numkey = nullptr;
+    uint64_t *t_off = nullptr;
+    uint32_t *perm = nullptr;
+    uint32_t *blk_hist = nullptr;
+    uint64_t *blk_off = nullptr, *partial = nullptr, *bin_off = nullptr;
+    unsigned long long *zero_count = nullptr;
+    uint32_t pblocks = 0;
+    uint64_t nnz_structural = 0;
+  } plan;
+  size_t arena_used = 0;
+};
+
+static constexpr size_t PINNED_BYTES = 8192;
+static constexpr size_t POOL_LIMIT_BLOCKS = 16;
+
+// ---- helpers ------------------------------------------------------------------------------------
+static int set_device(const spgemm_ctx *ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return SPGEMM_OK;
+}
+
+static int grow(spgemm_ctx *ctx, Growable &g, size_t bytes) {
+  if (bytes <= g.cap) return SPGEMM_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (g.p) HIP_TRY(hipFree(g.p));
+  g.p = nullptr;
+  g.cap = 0;
+  size_t want = bytes + bytes / 8 + 4096;
+  HIP_TRY(hipMalloc(&g.p, want));
+  g.cap = want;
+  return SPGEMM_OK;
+}
+
+static int pool_alloc(spgemm_ctx *ctx, size_t bytes, void **out, size_t *got) {
+  if (bytes == 0) bytes = 256;
+  int best = -1;
+  for (size_t i = 0; i < ctx->pool.size(); ++i)
+    if (ctx->pool[i].bytes >= bytes && (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = (int)i;
+  if (best >= 0 && ctx->pool[best].bytes <= bytes + bytes / 2 + (1 << 20)) {
+    *out = ctx->pool[best].p;
+    *got = ctx->pool[best].bytes;
+    ctx->pool_bytes -= ctx->pool[best].bytes;
+    ctx->pool.erase(ctx->pool.begin() + best);
+    return SPGEMM_OK;
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && !ctx->pool.empty()) {
+    for (auto &b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    e = hipMalloc(out, bytes);
+  }
+  if (e != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? SPGEMM_ERR_NOMEM : SPGEMM_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  *got = bytes;
+  return SPGEMM_OK;
+}
+
+static void pool_release(spgemm_ctx *ctx, void *p, size_t bytes) {
+  if (!p) return;
+  if (ctx->pool.size() >= POOL_LIMIT_BLOCKS) {
+    // drop the smallest block
+    size_t s = 0;
+    for (size_t i = 1; i < ctx->pool.size(); ++i)
+      if (ctx->pool[i].bytes < ctx->pool[s].bytes) s = i;
+    (void)hipFree(ctx->pool[s].p);
+    ctx->pool_bytes -= ctx->pool[s].bytes;
+    ctx->pool.erase(ctx->pool.begin() + s);
+  }
+  ctx->pool.push_back({p, bytes});
+  ctx->pool_bytes += bytes;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct ArenaCursor {
+  char *base;
+  size_t used;
+  size_t cap;
+  template <class T> T *take(size_t n) {
+    size_t bytes = align_up(n * sizeof(T), 256);
+    T *p = reinterpret_cast<T *>(base + used);
+    used += bytes;
+    return p;
+  }
+};
+
+static uint32_t div_up_u64(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// exclusive scan of n uint32 -> out[n+1] uint64, using `partial` (nparts + 1 uint64)
+static uint32_t scan_parts(uint64_t n) { return div_up_u64(n ? n : 1, (uint64_t)SCAN_BLOCK * SCAN_ITEMS); }
+
+static int launch_scan(spgemm_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *partial) {
+  uint32_t nparts = scan_parts(n);
+  hipLaunchKernelGGL(k_scan_partials, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, ctx->stream, partial, nparts);
+  hipLaunchKernelGGL(k_scan_final, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial, out, nparts);
+  HIP_TRY(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+// stable partition of rows by key; bin_off (nbins + 1 uint64, device)
+struct PartScratch {
+  uint32_t nblocks;
+  uint32_t *blk_hist;
+  uint64_t *blk_off;
+  uint64_t *partial;
+};
+
+static uint32_t part_blocks(uint64_t n) { return div_up_u64(n ? n : 1, (uint64_t)PART_BLOCK * PART_ROUNDS); }
+
+static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uint32_t nbins, PartScratch ps,
+                            uint32_t *rows_out, uint64_t *bin_off) {
+  uint32_t nb = ps.nblocks;
+  hipLaunchKernelGGL(k_part_hist, dim3(nb), dim3(PART_BLOCK), 0, ctx->stream, key, n, nbins, nb, ps.blk_hist);
+  TRY(launch_scan(ctx, ps.blk_hist, (uint64_t)nbins * nb, ps.blk_off, ps.partial));
+  hipLaunchKernelGGL(k_part_scatter, dim3(nb), dim3(PART_BLOCK), 0, ctx->stream, key, n, nbins, nb, ps.blk_off,
+                     rows_out);
+  hipLaunchKernelGGL(k_part_binoff, dim3(1), dim3(MAX_BINS + 1 <= 256 ? 256 : 512), 0, ctx->stream, ps.blk_off, nbins,
+                     nb, bin_off);
+  HIP_TRY(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_rowinfo) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  TRY(pool_alloc(ctx, std::max<uint64_t>(B->rows, 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
+  if (B->rows) {
+    uint32_t blocks = div_up_u64(B->rows * 8, 256);
+    hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
+                       mb->d_rowinfo);
+    HIP_TRY(hipGetLastError());
+  }
+  return SPGEMM_OK;
+}
+
+// ---- kernel dispatch by lane-group size ------------------------------------------------------------
+template <class... Args> struct Launcher {
+  template <void (*K8)(Args...), void (*K16)(Args...), void (*K32)(Args...), void (*K64)(Args...)>
+  static void go(uint32_t gsel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    switch (gsel) {
+    case 0: hipLaunchKernelGGL(K8, grid, block, lds, s, args...); break;
+    case 1: hipLaunchKernelGGL(K16, grid, block, lds, s, args...); break;
+    case 2: hipLaunchKernelGGL(K32, grid, block, lds, s, args...); break;
+    default: hipLaunchKernelGGL(K64, grid, block, lds, s, args...); break;
+    }
+  }
+};
+
+static bool g_attr_set = false;
+template <class K> static void raise_lds_limit(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+}
+static void raise_all_lds_limits() {
+  if (g_attr_set) return;
+  raise_lds_limit(k_sym_window<8>); raise_lds_limit(k_sym_window<16>);
+  raise_lds_limit(k_sym_window<32>); raise_lds_limit(k_sym_window<64>);
+  raise_lds_limit(k_sym_hash<8>); raise_lds_limit(k_sym_hash<16>);
+  raise_lds_limit(k_sym_hash<32>); raise_lds_limit(k_sym_hash<64>);
+  raise_lds_limit(k_num_window<8>); raise_lds_limit(k_num_window<16>);
+  raise_lds_limit(k_num_window<32>); raise_lds_limit(k_num_window<64>);
+  raise_lds_limit(k_num_hash<8>); raise_lds_limit(k_num_hash<16>);
+  raise_lds_limit(k_num_hash<32>); raise_lds_limit(k_num_hash<64>);
+  g_attr_set = true;
+}
+
+// ---- library ------------------------------------------------------------------------------------
+extern "C" int spgemm_version(void) { return 100; }
+extern "C" const char *spgemm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int spgemm_device_count(int *count) {
+  if (!count) return fail(SPGEMM_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(SPGEMM_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_create(int device, spgemm_ctx **out) {
+  if (!out) return fail(SPGEMM_ERR_INVALID, "ctx out pointer is NULL");
+  *out = nullptr;
+  int n = 0;
+  TRY(spgemm_device_count(&n));
+  if (n <= 0) return fail(SPGEMM_ERR_HIP, "no HIP device is visible; this library has no CPU path");
+  if (device < 0 || device >= n) return fail(SPGEMM_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  spgemm_ctx *ctx = new (std::nothrow) spgemm_ctx();
+  if (!ctx) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  ctx->device = device;
+  ctx->cp.win_max_span = 65536;
+  ctx->cp.win_ratio = 128;
+  ctx->cp.hash_max_nprod = 4096;
+  ctx->cp.g_thresh0 = 6;
+  ctx->cp.g_thresh1 = 12;
+  ctx->cp.g_thresh2 = 24;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(SPGEMM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  ctx->stream = ctx->own_stream;
+  for (auto &ev : ctx->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(SPGEMM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+    }
+  }
+  e = hipHostMalloc(&ctx->h_pinned, PINNED_BYTES);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(SPGEMM_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+  }
+  e = hipMalloc((void **)&ctx->d_small, 4096);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(SPGEMM_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  raise_all_lds_limits();
+  *out = ctx;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
+  if (!ctx) return SPGEMM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &b : ctx->pool) (void)hipFree(b.p);
+  if (ctx->arena.p) (void)hipFree(ctx->arena.p);
+  if (ctx->temp_cols.p) (void)hipFree(ctx->temp_cols.p);
+  if (ctx->gscratch.p) (void)hipFree(ctx->gscratch.p);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->d_small) (void)hipFree(ctx->d_small);
+  for (auto &ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream) {
+  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
+  TRY(set_device(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->plan.valid = false;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_synchronize(spgemm_ctx *ctx) {
+  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
+  TRY(set_device(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return fail(SPGEMM_ERR_INVALID, "ctx or name is NULL");
+  std::string n(name);
+  if (value < 0) return fail(SPGEMM_ERR_INVALID, "option %s: negative value", name);
+  if (n == "window_max_span") {
+    if (value > 65536) return fail(SPGEMM_ERR_INVALID, "window_max_span is at most 65536");
+    ctx->cp.win_max_span = (uint32_t)value;
+  } else if (n == "window_ratio") {
+    ctx->cp.win_ratio = (uint32_t)value;
+  } else if (n == "hash_max_nprod") {
+    if (value > 4096) return fail(SPGEMM_ERR_INVALID, "hash_max_nprod is at most 4096");
+    ctx->cp.hash_max_nprod = (uint32_t)value;
+  } else if (n == "g_thresh0") {
+    ctx->cp.g_thresh0 = (uint32_t)value;
+  } else if (n == "g_thresh1") {
+    ctx->cp.g_thresh1 = (uint32_t)value;
+  } else if (n == "g_thresh2") {
+    ctx->cp.g_thresh2 = (uint32_t)value;
+  } else if (n == "lds_budget") {
+    if (value < 8192 || value > 160 * 1024) return fail(SPGEMM_ERR_INVALID, "lds_budget must be 8192..163840");
+    ctx->lds_budget = (size_t)value;
+  } else if (n == "global_blocks_sym") {
+    if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "global_blocks_sym must be 1..4096");
+    ctx->global_blocks_sym = (uint32_t)value;
+  } else if (n == "global_blocks_num") {
+    if (value < 1 || value > 16384) return fail(SPGEMM_ERR_INVALID, "global_blocks_num must be 1..16384");
+    ctx->global_blocks_num = (uint32_t)value;
+  } else {
+    return fail(SPGEMM_ERR_INVALID, "unknown option %s", name);
+  }
+  ctx->plan.valid = false;
+  return SPGEMM_OK;
+}
+
+// ---- matrices -----------------------------------------------------------------------------------
+static int validate_device(spgemm_ctx *ctx, const spgemm_mat *m) {
+  uint32_t *d_bad = ctx->d_small;
+  HIP_TRY(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+  uint64_t work = std::max<uint64_t>(m->rows, m->nnz);
+  uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(work ? work : 1, 256), 4096);
+  hipLaunchKernelGGL(k_validate, dim3(blocks), dim3(256), 0, ctx->stream, m->rows, m->cols, m->nnz, m->d_ptr,
+                     m->d_col, d_bad);
+  HIP_TRY(hipGetLastError());
+  uint32_t bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (bad & 3u) return fail(SPGEMM_ERR_INVALID, "row_ptr is not a monotone 0..nnz sequence");
+  if (bad & 4u) return fail(SPGEMM_ERR_INVALID, "col_idx holds an index >= cols");
+  return SPGEMM_OK;
+}
+
+static int check_dims(uint64_t rows, uint64_t cols) {
+  if (rows >= 0xFFFFFFFFull || cols >= 0xFFFFFFFFull)
+    return fail(SPGEMM_ERR_UNSUPPORTED, "rows and cols must be below 2^32 - 1 (row/column ids are 32 bit)");
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_from_host(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz,
+                                    const uint64_t *row_ptr, const uint32_t *col_idx, const double *val,
+                                    spgemm_mat **out) {
+  if (!ctx || !out || !row_ptr || (nnz && (!col_idx || !val))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  TRY(check_dims(rows, cols));
+  if (row_ptr[0] != 0 || row_ptr[rows] != nnz) return fail(SPGEMM_ERR_INVALID, "row_ptr[0] != 0 or row_ptr[rows] != nnz");
+  for (uint64_t r = 0; r < rows; ++r)
+    if (row_ptr[r] > row_ptr[r + 1]) return fail(SPGEMM_ERR_INVALID, "row_ptr decreases at row %llu", (unsigned long long)r);
+  for (uint64_t j = 0; j < nnz; ++j)
+    if (col_idx[j] >= cols) return fail(SPGEMM_ERR_INVALID, "col_idx[%llu] = %u >= cols", (unsigned long long)j, col_idx[j]);
+  TRY(set_device(ctx));
+  spgemm_mat *m = new (std::nothrow) spgemm_mat();
+  if (!m) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  m->rows = rows; m->cols = cols; m->nnz = nnz; m->owns = true; m->device = ctx->device;
+  int rc = pool_alloc(ctx, (rows + 1) * 8, (void **)&m->d_ptr, &m->bytes_ptr);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 4, (void **)&m->d_col, &m->bytes_col);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 8, (void **)&m->d_val, &m->bytes_val);
+  if (rc != SPGEMM_OK) { spgemm_mat_free(ctx, m); return rc; }
+  hipError_t e = hipMemcpyAsync(m->d_ptr, row_ptr, (rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->d_col, col_idx, nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz) e = hipMemcpyAsync(m->d_val, val, nnz * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    spgemm_mat_free(ctx, m);
+    return fail(SPGEMM_ERR_HIP, "host to device copy failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_wrap_device(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz,
+                                      const uint64_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_val,
+                                      int validate, spgemm_mat **out) {
+  if (!ctx || !out || !d_row_ptr || (nnz && (!d_col_idx || !d_val))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  TRY(check_dims(rows, cols));
+  TRY(set_device(ctx));
+  spgemm_mat *m = new (std::nothrow) spgemm_mat();
+  if (!m) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  m->rows = rows; m->cols = cols; m->nnz = nnz; m->owns = false; m->device = ctx->device;
+  m->d_ptr = const_cast<uint64_t *>(d_row_ptr);
+  m->d_col = const_cast<uint32_t *>(d_col_idx);
+  m->d_val = const_cast<double *>(d_val);
+  if (validate) {
+    int rc = validate_device(ctx, m);
+    if (rc != SPGEMM_OK) { delete m; return rc; }
+  }
+  *out = m;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_info(const spgemm_mat *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz) {
+  if (!m) return fail(SPGEMM_ERR_INVALID, "matrix is NULL");
+  if (rows) *rows = m->rows;
+  if (cols) *cols = m->cols;
+  if (nnz) *nnz = m->nnz;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_device_ptrs(const spgemm_mat *m, const uint64_t **d_row_ptr, const uint32_t **d_col_idx,
+                                      const double **d_val) {
+  if (!m) return fail(SPGEMM_ERR_INVALID, "matrix is NULL");
+  if (d_row_ptr) *d_row_ptr = m->d_ptr;
+  if (d_col_idx) *d_col_idx = m->d_col;
+  if (d_val) *d_val = m->d_val;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *row_ptr, uint32_t *col_idx,
+                                  double *val) {
+  if (!ctx || !m) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  if (row_ptr) HIP_TRY(hipMemcpyAsync(row_ptr, m->d_ptr, (m->rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (col_idx && m->nnz) HIP_TRY(hipMemcpyAsync(col_idx, m->d_col, m->nnz * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (val && m->nnz) HIP_TRY(hipMemcpyAsync(val, m->d_val, m->nnz * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
+  if (!m) return SPGEMM_OK;
+  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
+  (void)hipSetDevice(ctx->device);
+  if (ctx->plan.valid && (ctx->plan.A == m || ctx->plan.B == m)) ctx->plan.valid = false;
+  if (m->d_rowinfo) {
+    (void)hipStreamSynchronize(ctx->stream);
+    pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
+  }
+  if (m->owns) {
+    (void)hipStreamSynchronize(ctx->stream);
+    pool_release(ctx, m->d_ptr, m->bytes_ptr);
+    pool_release(ctx, m->d_col, m->bytes_col);
+    pool_release(ctx, m->d_val, m->bytes_val);
+  }
+  delete m;
+  return SPGEMM_OK;
+}
+
+// ---- the multiply -------------------------------------------------------------------------------
+struct HostCounts {
+  uint64_t bin_off[MAX_BINS + 1];
+  uint64_t total_a; // total_ub (symbolic phase) or nnz (numeric phase)
+  uint64_t total_nprod;
+  uint32_t long_count;
+  uint32_t pad;
+};
+static_assert(sizeof(HostCounts) <= PINNED_BYTES, "pinned staging buffer too small");
+
+static uint32_t threads_for(uint32_t groups, uint32_t G) { return (uint32_t)align_up((size_t)groups * G, 64); }
+
+// symbolic phase: analysis, binning, per-bin symbolic kernels, scan of the row counts.
+// On success ctx->plan describes the row arrays (in ctx->arena) and d_row_ptr holds the
+// structural row pointer.
+static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *d_row_ptr) {
+  if (A->cols != B->rows) return fail(SPGEMM_ERR_INVALID, "A.cols (%llu) != B.rows (%llu)", (unsigned long long)A->cols, (unsigned long long)B->rows);
+  if (A->device != ctx->device || B->device != ctx->device) return fail(SPGEMM_ERR_INVALID, "matrix lives on another device");
+  ctx->plan.valid = false;
+  const uint32_t rows = (uint32_t)A->rows;
+  spgemm_stats &st = ctx->stats;
+  memset(&st, 0, sizeof(st));
+  st.rows_a = A->rows; st.nnz_a = A->nnz; st.nnz_b = B->nnz;
+  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  if (rows == 0) {
+    HIP_TRY(hipMemsetAsync(d_row_ptr, 0, 8, ctx->stream));
+    for (int i = 1; i <= 2; ++i) HIP_TRY(hipEventRecord(ctx->ev[i], ctx->stream));
+    ctx->plan = spgemm_ctx::Plan();
+    ctx->plan.valid = true; ctx->plan.A = A; ctx->plan.B = B;
+    return SPGEMM_OK;
+  }
+  TRY(ensure_rowinfo(ctx, B));
+
+  // arena layout
+  const uint32_t pblocks = part_blocks(rows);
+  const size_t hist_n = (size_t)MAX_BINS * pblocks;
+  const uint32_t max_long = (uint32_t)std::min<uint64_t>(rows, A->nnz / (ctx->long_len + 1) + 1);
+  size_t need = 0;
+  need += 4 * align_up((size_t)rows * 4, 256);            // cmin, cmax, ub, nnz
+  need += 2 * align_up((size_t)rows, 256);                // key, numkey
+  need += align_up((size_t)rows * 4, 256);                // perm
+  need += align_up(((size_t)rows + 1) * 8, 256);          // t_off
+  need += align_up((size_t)max_long * 4, 256) + 256;      // long rows + counter
+  need += align_up(hist_n * 4, 256) + align_up((hist_n + 1) * 8, 256); // partition histogram + scan
+  need += align_up(((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2) * 8, 256); // scan partials
+  need += align_up((MAX_BINS + 1) * 8, 256) + 256 + 256 + 256; // bin_off, counters
+  TRY(grow(ctx, ctx->arena, need));
+  ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
+  uint32_t *r_cmin = ar.take<uint32_t>(rows), *r_cmax = ar.take<uint32_t>(rows);
+  uint32_t *r_ub = ar.take<uint32_t>(rows), *r_nnz = ar.take<uint32_t>(rows);
+  uint8_t *r_key = ar.take<uint8_t>(rows), *r_numkey = ar.take<uint8_t>(rows);
+  uint32_t *perm = ar.take<uint32_t>(rows);
+  uint64_t *t_off = ar.take<uint64_t>((size_t)rows + 1);
+  uint32_t *long_rows = ar.take<uint32_t>(max_long);
+  uint32_t *long_count = ar.take<uint32_t>(64);
+  uint32_t *blk_hist = ar.take<uint32_t>(hist_n);
+  uint64_t *blk_off = ar.take<uint64_t>(hist_n + 1);
+  uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2);
+  uint64_t *bin_off = ar.take<uint64_t>(MAX_BINS + 1);
+  uint64_t *total_nprod = ar.take<uint64_t>(32);
+  unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32));
+  ctx->arena_used = ar.used;
+  if (ar.used > ar.cap) return fail(SPGEMM_ERR_STATE, "internal: arena layout exceeds its size");
+
+  HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
+  HIP_TRY(hipMemsetAsync(total_nprod, 0, 256, ctx->stream));
+  HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
+  HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
+
+  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, nullptr, total_nprod, long_rows, long_count};
+  hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
+                     A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
+  if (max_long > 1 || A->nnz > ctx->long_len)
+    hipLaunchKernelGGL(k_analyze_long, dim3(std::min<uint32_t>(max_long, 1024)), dim3(256), 0, ctx->stream, A->d_ptr,
+                       A->d_col, B->d_rowinfo, ao, ctx->cp);
+  HIP_TRY(hipGetLastError());
+  TRY(launch_scan(ctx, r_ub, rows, t_off, partial));
+  PartScratch ps{pblocks, blk_hist, blk_off, partial};
+  TRY(launch_partition(ctx, r_key, rows, SYM_NBINS, ps, perm, bin_off));
+
+  HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
+  HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (SYM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->total_nprod, total_nprod, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  st.nprod = hc->total_nprod;
+  const uint64_t total_ub = hc->total_a;
+  uint64_t boff[SYM_NBINS + 1];
+  memcpy(boff, hc->bin_off, sizeof(boff));
+  TRY(grow(ctx, ctx->temp_cols, std::max<uint64_t>(total_ub, 1) * 4));
+  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+
+  Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
+  RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey};
+
+  for (int key = 0; key < SYM_NBINS; ++key) {
+    uint64_t cnt64 = boff[key + 1] - boff[key];
+    if (!cnt64) continue;
+    uint32_t cnt = (uint32_t)cnt64;
+    const uint32_t *rows_bin = perm + boff[key];
+    uint32_t gsel = key & 3;
+    if (key < SYM_HASH0) {
+      uint32_t tier = key >> 2;
+      uint32_t words = (64u << tier) + 2u;
+      size_t region = (size_t)words * 4;
+      uint32_t wpb = 4;
+      st.rows_window += cnt;
+      Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, uint32_t>::go<k_sym_window<8>, k_sym_window<16>,
+                                                                            k_sym_window<32>, k_sym_window<64>>(
+          gsel, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
+    } else if (key < SYM_GLOBAL0) {
+      uint32_t tier = (key - SYM_HASH0) >> 2;
+      uint32_t log2s = 7 + 2 * tier;
+      size_t region = (size_t)8 << log2s;
+      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      st.rows_hash += cnt;
+      Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, uint32_t>::go<k_sym_hash<8>, k_sym_hash<16>,
+                                                                            k_sym_hash<32>, k_sym_hash<64>>(
+          gsel, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
+    } else {
+      uint64_t words_total = (B->cols + 31) / 32 + 1;
+      uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
+      size_t bytes = (size_t)blocks * words_total * 4;
+      if (bytes > ctx->gscratch.cap) {
+        TRY(grow(ctx, ctx->gscratch, std::max(bytes, (size_t)ctx->global_blocks_num * words_total * 8)));
+        HIP_TRY(hipMemsetAsync(ctx->gscratch.p, 0, ctx->gscratch.cap, ctx->stream));
+      }
+      st.rows_global += cnt;
+      hipLaunchKernelGGL(k_sym_global, dim3(blocks), dim3(256), 0, ctx->stream, rows_bin, cnt, cA, cB, rm,
+                         reinterpret_cast<uint32_t *>(ctx->gscratch.p), words_total);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  st.rows_empty = rows - st.rows_window - st.rows_hash - st.rows_global;
+  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+  TRY(launch_scan(ctx, r_nnz, rows, d_row_ptr, partial));
+
+  spgemm_ctx::Plan &pl = ctx->plan;
+  pl.A = A; pl.B = B;
+  pl.r_cmin = r_cmin; pl.r_cmax = r_cmax; pl.r_nnz = r_nnz;
+  pl.r_key = r_key; pl.r_numkey = r_numkey; pl.t_off = t_off; pl.perm = perm;
+  pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
+  pl.zero_count = zero_count; pl.pblocks = pblocks;
+  pl.valid = true;
+  return SPGEMM_OK;
+}
+
+// numeric phase; needs ctx->plan from run_symbolic on the same operands.
+static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *d_row_ptr,
+                       uint32_t *d_col, double *d_val, uint64_t nnz_structural, uint64_t *nnz_final,
+                       bool allow_realloc, spgemm_mat *Cmat) {
+  spgemm_ctx::Plan &pl = ctx->plan;
+  spgemm_stats &st = ctx->stats;
+  const uint32_t rows = (uint32_t)A->rows;
+  st.nnz_structural = nnz_structural;
+  *nnz_final = nnz_structural;
+  if (rows == 0 || nnz_structural == 0) {
+    for (int i = 3; i <= 5; ++i) HIP_TRY(hipEventRecord(ctx->ev[i], ctx->stream));
+    return SPGEMM_OK;
+  }
+  uint32_t *perm = pl.perm;
+  uint64_t *partial = pl.partial, *bin_off = pl.bin_off;
+  unsigned long long *zero_count = pl.zero_count;
+  PartScratch ps{pl.pblocks, pl.blk_hist, pl.blk_off, pl.partial};
+  TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, perm, bin_off));
+  HIP_TRY(hipMemsetAsync(zero_count, 0, 256, ctx->stream));
+  HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
+  HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (NUM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint64_t boff[NUM_NBINS + 1];
+  memcpy(boff, hc->bin_off, sizeof(boff));
+  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+
+  Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
+  RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
+             pl.r_numkey};
+  NumOut no{d_row_ptr, d_col, d_val, zero_count};
+  const size_t lds_max = 160 * 1024;
+
+  for (int key = 0; key < NUM_NBINS; ++key) {
+    uint64_t cnt64 = boff[key + 1] - boff[key];
+    if (!cnt64) continue;
+    uint32_t cnt = (uint32_t)cnt64;
+    const uint32_t *rows_bin = perm + boff[key];
+    if (key < NUM_GLOBAL) {
+      uint32_t gsel = key & 3;
+      size_t region;
+      uint32_t p0, p1 = 0;
+      bool window = key < NUM_HASH0;
+      if (window) {
+        uint32_t st_ = (key >> 2) >> 2, ct = (key >> 2) & 3;
+        p0 = (64u << st_) + 2u;   // words
+        p1 = 128u << (2 * ct);    // cap
+        region = (size_t)p0 * 8 + (size_t)p1 * 8;
+      } else {
+        uint32_t ct = ((key - NUM_HASH0) >> 2) & 3;
+        p0 = 7 + 2 * ct;          // log2 S
+        region = (size_t)10 << p0;
+      }
+      // Lanes per row: the requested group size, widened while one wavefront's groups would
+      // not fit the LDS of a workgroup.
+      while (gsel < 3 && (64u >> (3 + gsel)) * region > lds_max) ++gsel;
+      uint32_t G = 8u << gsel;
+      uint32_t gpb = (uint32_t)std::min<size_t>(256 / G, std::max<size_t>(1, ctx->lds_budget / region));
+      if ((size_t)gpb * region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
+      // use whole wavefronts: round the group count up to fill the last wavefront when it fits
+      uint32_t per_wave = 64 / G;
+      if (gpb % per_wave && (size_t)(gpb / per_wave + 1) * per_wave * region <= lds_max) gpb = (gpb / per_wave + 1) * per_wave;
+      gpb = std::min<uint32_t>(gpb, 256 / G);
+      dim3 grid(div_up_u64(cnt, gpb)), block(threads_for(gpb, G));
+      size_t lds = (size_t)gpb * region;
+      if (window) {
+        Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, NumOut, uint32_t, uint32_t, uint32_t>::go<
+            k_num_window<8>, k_num_window<16>, k_num_window<32>, k_num_window<64>>(gsel, grid, block, lds, ctx->stream,
+                                                                                  rows_bin, cnt, cA, cB, rm, no, p0, p1, gpb);
+      } else {
+        Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, NumOut, uint32_t, uint32_t>::go<
+            k_num_hash<8>, k_num_hash<16>, k_num_hash<32>, k_num_hash<64>>(gsel, grid, block, lds, ctx->stream, rows_bin,
+                                                                          cnt, cA, cB, rm, no, p0, gpb);
+      }
+    } else {
+      uint64_t words_total = (B->cols + 31) / 32 + 1;
+      uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
+      size_t bytes = (size_t)blocks * words_total * 8;
+      if (bytes > ctx->gscratch.cap) {
+        TRY(grow(ctx, ctx->gscratch, bytes));
+        HIP_TRY(hipMemsetAsync(ctx->gscratch.p, 0, ctx->gscratch.cap, ctx->stream));
+      }
+      hipLaunchKernelGGL(k_num_global, dim3(blocks), dim3(64), 0, ctx->stream, rows_bin, cnt, cA, cB, rm, no,
+                         reinterpret_cast<unsigned long long *>(ctx->gscratch.p), words_total);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->total_a, zero_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint64_t zeros = hc->total_a;
+  if (zeros) {
+    // Entries that summed to exactly 0.0 are dropped, as Cells::add erases them
+    // (reference include/matrix_impl.hpp:90-93).
+    uint64_t keep_nnz = nnz_structural - zeros;
+    uint32_t *keep = pl.r_nnz; // reuse: per-row surviving count
+    hipLaunchKernelGGL(k_count_nonzero, dim3(div_up_u64((uint64_t)rows * 8, 256)), dim3(256), 0, ctx->stream, rows,
+                       d_row_ptr, d_val, keep);
+    void *ncol = nullptr, *nval = nullptr, *nptr = nullptr;
+    size_t bcol = 0, bval = 0, bptr = 0;
+    TRY(pool_alloc(ctx, keep_nnz * 4, &ncol, &bcol));
+    TRY(pool_alloc(ctx, keep_nnz * 8, &nval, &bval));
+    TRY(pool_alloc(ctx, ((size_t)rows + 1) * 8, &nptr, &bptr));
+    TRY(launch_scan(ctx, keep, rows, (uint64_t *)nptr, partial));
+    hipLaunchKernelGGL(k_compact_rows, dim3(div_up_u64((uint64_t)rows * 64, 256)), dim3(256), 0, ctx->stream, rows,
+                       d_row_ptr, d_col, d_val, (const uint64_t *)nptr, (uint32_t *)ncol, (double *)nval);
+    HIP_TRY(hipGetLastError());
+    if (allow_realloc && Cmat) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      pool_release(ctx, Cmat->d_ptr, Cmat->bytes_ptr);
+      pool_release(ctx, Cmat->d_col, Cmat->bytes_col);
+      pool_release(ctx, Cmat->d_val, Cmat->bytes_val);
+      Cmat->d_ptr = (uint64_t *)nptr; Cmat->bytes_ptr = bptr;
+      Cmat->d_col = (uint32_t *)ncol; Cmat->bytes_col = bcol;
+      Cmat->d_val = (double *)nval; Cmat->bytes_val = bval;
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_row_ptr, nptr, ((size_t)rows + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      if (keep_nnz) {
+        HIP_TRY(hipMemcpyAsync(d_col, ncol, keep_nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_val, nval, keep_nnz * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      pool_release(ctx, nptr, bptr);
+      pool_release(ctx, ncol, bcol);
+      pool_release(ctx, nval, bval);
+    }
+    *nnz_final = keep_nnz;
+    pl.valid = false; // r_nnz was overwritten
+  }
+  HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+  return SPGEMM_OK;
+}
+
+static int finish_stats(spgemm_ctx *ctx, uint64_t rows_c, uint64_t nnz_final) {
+  spgemm_stats &st = ctx->stats;
+  HIP_TRY(hipEventSynchronize(ctx->ev[5]));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); st.ms_analyze = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); st.ms_symbolic = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); st.ms_scan = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_numeric = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); st.ms_compact = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[5])); st.ms_total = ms;
+  st.nnz_c = nnz_final;
+  st.bytes_algorithmic = 12ull * (st.nnz_a + st.nprod + st.nnz_c) + 4ull * (st.rows_a + 1) + 8ull * (rows_c + 1);
+  st.temp_bytes = ctx->arena.cap + ctx->temp_cols.cap + ctx->gscratch.cap;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_multiply(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, spgemm_mat **out) {
+  if (!ctx || !A || !B || !out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  TRY(set_device(ctx));
+  spgemm_mat *C = new (std::nothrow) spgemm_mat();
+  if (!C) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  C->rows = A->rows; C->cols = B->cols; C->owns = true; C->device = ctx->device;
+  int rc = pool_alloc(ctx, (A->rows + 1) * 8, (void **)&C->d_ptr, &C->bytes_ptr);
+  if (rc == SPGEMM_OK) rc = run_symbolic(ctx, A, B, C->d_ptr);
+  uint64_t nnz_s = 0;
+  if (rc == SPGEMM_OK) {
+    hipError_t e = hipMemcpyAsync(ctx->h_pinned, C->d_ptr + A->rows, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "reading nnz failed: %s", hipGetErrorString(e));
+    nnz_s = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+  }
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz_s * 4, (void **)&C->d_col, &C->bytes_col);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz_s * 8, (void **)&C->d_val, &C->bytes_val);
+  uint64_t nnz_f = 0;
+  if (rc == SPGEMM_OK) rc = run_numeric(ctx, A, B, C->d_ptr, C->d_col, C->d_val, nnz_s, &nnz_f, true, C);
+  if (rc == SPGEMM_OK) rc = finish_stats(ctx, C->rows, nnz_f);
+  ctx->plan.valid = false;
+  if (rc != SPGEMM_OK) {
+    std::string keep = g_err;
+    spgemm_mat_free(ctx, C);
+    g_err = keep;
+    return rc;
+  }
+  C->nnz = nnz_f;
+  *out = C;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *d_row_ptr,
+                               uint64_t *nnz_structural) {
+  if (!ctx || !A || !B || !d_row_ptr || !nnz_structural) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  TRY(run_symbolic(ctx, A, B, d_row_ptr));
+  HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_row_ptr + A->rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *nnz_structural = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+  ctx->plan.nnz_structural = *nnz_structural;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *d_row_ptr,
+                              uint32_t *d_col_idx, double *d_val, uint64_t *nnz_final) {
+  if (!ctx || !A || !B || !d_row_ptr || !nnz_final) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (!ctx->plan.valid || ctx->plan.A != A || ctx->plan.B != B)
+    return fail(SPGEMM_ERR_STATE, "spgemm_numeric must follow spgemm_symbolic on the same operands");
+  if (ctx->plan.nnz_structural && (!d_col_idx || !d_val)) return fail(SPGEMM_ERR_INVALID, "output buffers are NULL");
+  TRY(set_device(ctx));
+  uint64_t nnz_f = 0;
+  TRY(run_numeric(ctx, A, B, d_row_ptr, d_col_idx, d_val, ctx->plan.nnz_structural, &nnz_f, false, nullptr));
+  TRY(finish_stats(ctx, A->rows, nnz_f));
+  ctx->plan.valid = false;
+  *nnz_final = nnz_f;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out) {
+  if (!ctx || !out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = ctx->stats;
+  return SPGEMM_OK;
+}
+
+// ---- section bitmap --------------------------------------------------------------------------------
+extern "C" int spgemm_section_bitmap(spgemm_ctx *ctx, const spgemm_mat *A, uint32_t n_sections, uint64_t *words_out) {
+  if (!ctx || !A || !words_out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (n_sections == 0 || n_sections > MAX_SECTIONS) return fail(SPGEMM_ERR_INVALID, "n_sections must be 1..%u", MAX_SECTIONS);
+  uint32_t section_width = (uint32_t)(A->cols / n_sections);
+  if (section_width == 0) return fail(SPGEMM_ERR_INVALID, "A.cols / n_sections == 0 (fewer columns than sections)");
+  TRY(set_device(ctx));
+  uint32_t nwords64 = (n_sections + 63) / 64;
+  uint32_t *d_words = ctx->d_small;
+  HIP_TRY(hipMemsetAsync(d_words, 0, (size_t)nwords64 * 8, ctx->stream));
+  if (A->nnz) {
+    uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(A->nnz, 256 * 8), 2048);
+    hipLaunchKernelGGL(k_section_bitmap, dim3(blocks), dim3(256), 0, ctx->stream, A->nnz, A->d_col, section_width,
+                       n_sections, d_words);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(words_out, d_words, (size_t)nwords64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+// ---- partitions (host) -------------------------------------------------------------------------------
+extern "C" int spgemm_partition_naive(uint32_t height, uint32_t width, int n_parts, spgemm_partition *out) {
+  if (!out || n_parts <= 0) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  uint32_t P = (uint32_t)n_parts;
+  uint32_t rpp = height / P, er = height % P, cpp = width / P, ec = width % P;
+  uint32_t cr = 0, cc = 0;
+  for (uint32_t i = 0; i < P; ++i) {
+    uint32_t tr = rpp + (i < er ? 1u : 0u), tc = cpp + (i < ec ? 1u : 0u);
+    out[i].start_row = cr; out[i].end_row = cr + tr;
+    out[i].start_col = cc; out[i].end_col = cc + tc;
+    cr += tr; cc += tc;
+  }
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_partition_balanced(const uint64_t *row_weight, uint32_t height, uint32_t width, int n_parts,
+                                         spgemm_partition *out) {
+  if (!out || n_parts <= 0 || (height && !row_weight)) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  uint32_t P = (uint32_t)n_parts;
+  TRY(spgemm_partition_naive(0, width, n_parts, out)); // columns are always split evenly
+  unsigned __int128 total = 0;
+  for (uint32_t r = 0; r < height; ++r) total += row_weight[r];
+  uint64_t per = (uint64_t)(total / P);
+  uint32_t node = 0;
+  uint64_t run = 0;
+  out[0].start_row = 0;
+  for (uint32_t r = 0; r < height && node + 1 < P; ++r) {
+    run += row_weight[r];
+    if (run > per) { // the row that crosses the share opens the next part
+      run = 0;
+      out[node].end_row = r;
+      out[node + 1].start_row = r;
+      ++node;
+    }
+  }
+  out[node].end_row = height;
+  for (uint32_t j = node + 1; j < P; ++j) out[j].start_row = out[j].end_row = height;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *row_nprod_out) {
+  if (!ctx || !A || !B || !row_nprod_out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (A->cols != B->rows) return fail(SPGEMM_ERR_INVALID, "A.cols != B.rows");
+  TRY(set_device(ctx));
+  const uint32_t rows = (uint32_t)A->rows;
+  if (!rows) return SPGEMM_OK;
+  TRY(ensure_rowinfo(ctx, B));
+  ctx->plan.valid = false;
+  size_t need = 3 * align_up((size_t)rows * 4, 256) + align_up(rows, 256) + align_up((size_t)rows * 8, 256) + 1024;
+  const uint32_t max_long = rows;
+  need += align_up((size_t)max_long * 4, 256);
+  TRY(grow(ctx, ctx->arena, need));
+  ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
+  uint32_t *c0 = ar.take<uint32_t>(rows), *c1 = ar.take<uint32_t>(rows), *ub = ar.take<uint32_t>(rows);
+  uint8_t *key = ar.take<uint8_t>(rows);
+  uint64_t *np = ar.take<uint64_t>(rows);
+  uint32_t *long_rows = ar.take<uint32_t>(max_long);
+  uint32_t *long_count = ar.take<uint32_t>(64);
+  uint64_t *total = ar.take<uint64_t>(32);
+  HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
+  HIP_TRY(hipMemsetAsync(total, 0, 256, ctx->stream));
+  AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count};
+  hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
+                     A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
+  hipLaunchKernelGGL(k_analyze_long, dim3(256), dim3(256), 0, ctx->stream, A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(row_nprod_out, np, (size_t)rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+// ---- shuffle (host) -----------------------------------------------------------------------------------
+// Fisher-Yates driven by splitmix64, written out so that every build gives the same permutation
+// for a seed (std::shuffle's use of the engine is implementation defined).
+extern "C" int spgemm_shuffle_random(uint32_t n, uint64_t seed, uint32_t *perm_out) {
+  if (n && !perm_out) return fail(SPGEMM_ERR_INVALID, "perm_out is NULL");
+  for (uint32_t i = 0; i < n; ++i) perm_out[i] = i;
+  uint64_t s = seed;
+  auto next = [&s]() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  for (uint32_t i = n; i > 1; --i) {
+    uint32_t j = (uint32_t)(((unsigned __int128)next() * i) >> 64);
+    std::swap(perm_out[i - 1], perm_out[j]);
+  }
+  return SPGEMM_OK;
+}
+
+// ---- operand selection --------------------------------------------------------------------------------
+extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uint32_t *keep_rows, uint64_t n_keep_rows,
+                                 const uint32_t *col_new_id, uint64_t new_cols, int sort_rows, spgemm_mat **out) {
+  if (!ctx || !M || !out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  TRY(set_device(ctx));
+  ctx->plan.valid = false;
+  const uint64_t n_out = keep_rows ? n_keep_rows : M->rows;
+  const uint64_t cols_out = col_new_id ? new_cols : M->cols;
+  TRY(check_dims(n_out, cols_out));
+  if (keep_rows)
+    for (uint64_t r = 0; r < n_out; ++r)
+      if (keep_rows[r] >= M->rows) return fail(SPGEMM_ERR_INVALID, "keep_rows[%llu] out of range", (unsigned long long)r);
+  if (col_new_id)
+    for (uint64_t c = 0; c < M->cols; ++c)
+      if (col_new_id[c] != 0xFFFFFFFFu && col_new_id[c] >= cols_out)
+        return fail(SPGEMM_ERR_INVALID, "col_new_id[%llu] out of range", (unsigned long long)c);
+  // scratch: keep_rows, col_new_id, row lengths, scan partials
+  size_t need = align_up(n_out * 4 + 4, 256) * 2 + align_up(M->cols * 4 + 4, 256) +
+                align_up(((size_t)scan_parts(n_out) + 2) * 8, 256);
+  TRY(grow(ctx, ctx->arena, need));
+  ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
+  uint32_t *d_keep = ar.take<uint32_t>(n_out + 1);
+  uint32_t *d_len = ar.take<uint32_t>(n_out + 1);
+  uint32_t *d_new = ar.take<uint32_t>(M->cols + 1);
+  uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(n_out) + 2);
+  if (keep_rows && n_out) HIP_TRY(hipMemcpyAsync(d_keep, keep_rows, n_out * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (col_new_id && M->cols) HIP_TRY(hipMemcpyAsync(d_new, col_new_id, M->cols * 4, hipMemcpyHostToDevice, ctx->stream));
+  spgemm_mat *R = new (std::nothrow) spgemm_mat();
+  if (!R) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  R->rows = n_out; R->cols = cols_out; R->owns = true; R->device = ctx->device;
+  int rc = pool_alloc(ctx, (n_out + 1) * 8, (void **)&R->d_ptr, &R->bytes_ptr);
+  if (rc != SPGEMM_OK) { delete R; return rc; }
+  const uint32_t *kr = keep_rows ? d_keep : nullptr, *cn = col_new_id ? d_new : nullptr;
+  if (n_out) {
+    hipLaunchKernelGGL(k_select_count, dim3(div_up_u64(n_out * 8, 256)), dim3(256), 0, ctx->stream, n_out, kr, M->d_ptr,
+                       M->d_col, cn, d_len);
+    rc = launch_scan(ctx, d_len, n_out, R->d_ptr, partial);
+  } else {
+    hipError_t e = hipMemsetAsync(R->d_ptr, 0, 8, ctx->stream);
+    if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "memset failed");
+  }
+  uint64_t nnz = 0;
+  if (rc == SPGEMM_OK) {
+    hipError_t e = hipMemcpyAsync(ctx->h_pinned, R->d_ptr + n_out, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "reading nnz failed: %s", hipGetErrorString(e));
+    nnz = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+  }
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 4, (void **)&R->d_col, &R->bytes_col);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 8, (void **)&R->d_val, &R->bytes_val);
+  if (rc == SPGEMM_OK && n_out && nnz) {
+    hipLaunchKernelGGL(k_select_copy, dim3(div_up_u64(n_out * 64, 256)), dim3(256), 0, ctx->stream, n_out, kr, M->d_ptr,
+                       M->d_col, M->d_val, cn, (const uint64_t *)R->d_ptr, R->d_col, R->d_val);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "select copy failed: %s", hipGetErrorString(e));
+  }
+  if (rc != SPGEMM_OK) {
+    std::string keep = g_err;
+    spgemm_mat_free(ctx, R);
+    g_err = keep;
+    return rc;
+  }
+  R->nnz = nnz;
+  if (sort_rows && nnz) {
+    // Sorting rows by the new column ids: pull the matrix to the host, sort each row, push it
+    // back.  Set-up work, done once per operand before any timed multiply.
+    std::vector<uint64_t> ptr(n_out + 1);
+    std::vector<uint32_t> col(nnz);
+    std::vector<double> val(nnz);
+    TRY(spgemm_mat_to_host(ctx, R, ptr.data(), col.data(), val.data()));
+    std::vector<uint32_t> idx;
+    std::vector<uint32_t> c2;
+    std::vector<double> v2;
+    for (uint64_t r = 0; r < n_out; ++r) {
+      uint64_t j0 = ptr[r], len = ptr[r + 1] - ptr[r];
+      if (len < 2 || std::is_sorted(col.begin() + j0, col.begin() + j0 + len)) continue;
+      idx.resize(len);
+      std::iota(idx.begin(), idx.end(), 0u);
+      std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return col[j0 + a] < col[j0 + b]; });
+      c2.resize(len); v2.resize(len);
+      for (uint64_t t = 0; t < len; ++t) { c2[t] = col[j0 + idx[t]]; v2[t] = val[j0 + idx[t]]; }
+      std::copy(c2.begin(), c2.end(), col.begin() + j0);
+      std::copy(v2.begin(), v2.end(), val.begin() + j0);
+    }
+    HIP_TRY(hipMemcpyAsync(R->d_col, col.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(R->d_val, val.data(), nnz * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  *out = R;
+  return SPGEMM_OK;
+}
+
+// ---- B exchange helpers -----------------------------------------------------------------------------------
+// Row bounds of section s of a matrix with total_rows rows cut in n_sections
+// (reference include/matrix_impl.hpp:628-639).
+static void section_rows(uint64_t total_rows, uint32_t n_sections, uint32_t s, uint64_t *r0, uint64_t *r1) {
+  uint64_t sh = total_rows / n_sections;
+  *r0 = sh * s;
+  *r1 = (s == n_sections - 1) ? total_rows : sh * (s + 1);
+}
+
+static int fetch_row_ptr(spgemm_ctx *ctx, const spgemm_mat *M, std::vector<uint64_t> &ptr) {
+  ptr.resize(M->rows + 1);
+  HIP_TRY(hipMemcpyAsync(ptr.data(), M->d_ptr, (M->rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_section_nnz(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sections, uint64_t first_row,
+                                  uint64_t total_rows, uint64_t *nnz_out) {
+  if (!ctx || !M || !nnz_out || n_sections == 0) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  if (first_row + M->rows > total_rows) return fail(SPGEMM_ERR_INVALID, "row block exceeds total_rows");
+  if (total_rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "total_rows / n_sections == 0");
+  TRY(set_device(ctx));
+  std::vector<uint64_t> ptr;
+  TRY(fetch_row_ptr(ctx, M, ptr));
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    uint64_t r0, r1;
+    section_rows(total_rows, n_sections, s, &r0, &r1);
+    uint64_t lo = std::min(std::max(r0, first_row), first_row + M->rows) - first_row;
+    uint64_t hi = std::min(std::max(r1, first_row), first_row + M->rows) - first_row;
+    nnz_out[s] = ptr[hi] - ptr[lo];
+  }
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sections, uint64_t first_row,
+                                    uint64_t total_rows, const uint64_t *bitmap_words, uint32_t *d_row_len_out,
+                                    uint32_t *d_col_idx_out, double *d_val_out, uint64_t *rows_out, uint64_t *nnz_out) {
+  if (!ctx || !M || !bitmap_words || !rows_out || !nnz_out || n_sections == 0)
+    return fail(SPGEMM_ERR_INVALID, "bad argument");
+  if (first_row + M->rows > total_rows) return fail(SPGEMM_ERR_INVALID, "row block exceeds total_rows");
+  if (total_rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "total_rows / n_sections == 0");
+  TRY(set_device(ctx));
+  ctx->plan.valid = false;
+  std::vector<uint64_t> ptr;
+  TRY(fetch_row_ptr(ctx, M, ptr));
+  // row lengths of the whole block, once
+  TRY(grow(ctx, ctx->arena, align_up(M->rows * 4 + 4, 256)));
+  uint32_t *d_len = reinterpret_cast<uint32_t *>(ctx->arena.p);
+  if (M->rows) {
+    hipLaunchKernelGGL(k_row_len, dim3(div_up_u64(M->rows, 256)), dim3(256), 0, ctx->stream, M->rows, M->d_ptr, d_len);
+    HIP_TRY(hipGetLastError());
+  }
+  uint64_t rows_w = 0, nnz_w = 0;
+  // adjacent selected sections are copied as one run
+  uint32_t s = 0;
+  while (s < n_sections) {
+    if (!((bitmap_words[s >> 6] >> (s & 63)) & 1ull)) { ++s; continue; }
+    uint32_t e = s;
+    while (e + 1 < n_sections && ((bitmap_words[(e + 1) >> 6] >> ((e + 1) & 63)) & 1ull)) ++e;
+    uint64_t r0, r1, tmp;
+    section_rows(total_rows, n_sections, s, &r0, &tmp);
+    section_rows(total_rows, n_sections, e, &tmp, &r1);
+    uint64_t lo = std::min(std::max(r0, first_row), first_row + M->rows) - first_row;
+    uint64_t hi = std::min(std::max(r1, first_row), first_row + M->rows) - first_row;
+    if (hi > lo) {
+      uint64_t j0 = ptr[lo], j1 = ptr[hi];
+      if (d_row_len_out) HIP_TRY(hipMemcpyAsync(d_row_len_out + rows_w, d_len + lo, (hi - lo) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      if (j1 > j0) {
+        if (d_col_idx_out) HIP_TRY(hipMemcpyAsync(d_col_idx_out + nnz_w, M->d_col + j0, (j1 - j0) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_val_out) HIP_TRY(hipMemcpyAsync(d_val_out + nnz_w, M->d_val + j0, (j1 - j0) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      rows_w += hi - lo;
+      nnz_w += j1 - j0;
+    }
+    s = e + 1;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *rows_out = rows_w;
+  *nnz_out = nnz_w;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections, const uint64_t *bitmap_words,
+                                       const uint32_t *d_row_len_concat, uint64_t n_row_len, uint64_t *d_row_ptr_out,
+                                       uint64_t *nnz_out) {
+  if (!ctx || !bitmap_words || !d_row_ptr_out || n_sections == 0) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  if (rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "rows / n_sections == 0");
+  TRY(check_dims(rows, 0));
+  TRY(set_device(ctx));
+  ctx->plan.valid = false;
+  size_t need = align_up(rows * 4 + 4, 256) + align_up(((size_t)scan_parts(rows) + 2) * 8, 256);
+  TRY(grow(ctx, ctx->arena, need));
+  ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
+  uint32_t *d_len = ar.take<uint32_t>(rows + 1);
+  uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(rows) + 2);
+  HIP_TRY(hipMemsetAsync(d_len, 0, rows * 4, ctx->stream));
+  uint64_t src = 0;
+  uint32_t s = 0;
+  while (s < n_sections) {
+    if (!((bitmap_words[s >> 6] >> (s & 63)) & 1ull)) { ++s; continue; }
+    uint32_t e = s;
+    while (e + 1 < n_sections && ((bitmap_words[(e + 1) >> 6] >> ((e + 1) & 63)) & 1ull)) ++e;
+    uint64_t r0, r1, tmp;
+    section_rows(rows, n_sections, s, &r0, &tmp);
+    section_rows(rows, n_sections, e, &tmp, &r1);
+    if (src + (r1 - r0) > n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer shorter than the selected sections");
+    HIP_TRY(hipMemcpyAsync(d_len + r0, d_row_len_concat + src, (r1 - r0) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    src += r1 - r0;
+    s = e + 1;
+  }
+  if (src != n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer longer than the selected sections");
+  TRY(launch_scan(ctx, d_len, rows, d_row_ptr_out, partial));
+  if (nnz_out) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_row_ptr_out + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *nnz_out = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+  }
+  return SPGEMM_OK;
+}

@@ -1,0 +1,189 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Bar: row_ptr / col_idx identical; values identical bitwise (the kernels accumulate in the CPU
+loop's order with separate multiply and add), which is stricter than the 1e-12 relative
+tolerance the project states.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from spgemm_amd import capi, hostcsr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def to_ocsr(h):
+    return orc.OCsr(h.rows, h.cols, h.row_ptr, h.col_idx, h.val)
+
+
+def gpu_multiply(ctx, A, B):
+    dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    dB = dA if B is A else ctx.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
+    dC = ctx.multiply(dA, dB)
+    rp, ci, v = dC.to_host()
+    st = ctx.stats()
+    C = orc.OCsr(A.rows, B.cols, rp, ci, v)
+    dC.free()
+    if dB is not dA:
+        dB.free()
+    dA.free()
+    return C, st
+
+
+def check(ctx, A, B, expect_sorted=True):
+    C, st = gpu_multiply(ctx, A, B)
+    E, est = orc.spgemm(to_ocsr(A), to_ocsr(B), with_stats=True)
+    assert st["nprod"] == est["nprod"]
+    if expect_sorted:  # output rows come out sorted by column
+        assert np.array_equal(C.col_idx, C.canonical().col_idx)
+    orc.assert_same(C, E, rtol=0.0)
+    assert st["nnz_c"] == E.nnz
+    return C, st
+
+
+def test_reference_fixture_test(ctx, golden_dir):
+    A = hostcsr.read_mtx(f"{golden_dir}/ref_test/A.mtx")
+    B = hostcsr.read_mtx(f"{golden_dir}/ref_test/B.mtx")
+    C, _ = check(ctx, A, B)
+    orc.assert_same(C, orc.read_mtx(f"{golden_dir}/ref_test/C_expected.mtx"), rtol=0.0)
+
+
+def test_reference_fixture_first(ctx, golden_dir):
+    A = hostcsr.read_mtx(f"{golden_dir}/ref_first/A.mtx")
+    C, st = check(ctx, A, A)
+    orc.assert_same(C, orc.read_mtx(f"{golden_dir}/ref_first/C_expected.mtx"), rtol=0.0)
+    assert st["nnz_c"] == 3067
+
+
+@pytest.mark.parametrize("n,per_row,band", [(3000, 9, 40), (20000, 30, 300), (5000, 3, 2500)])
+def test_banded_window_path(ctx, n, per_row, band):
+    A = hostcsr.banded_random(n, per_row, band, seed=n)
+    _, st = check(ctx, A, A)
+    assert st["rows_window"] > 0
+
+
+@pytest.mark.parametrize("n", [4096, 100_000])
+def test_erdos_renyi(ctx, n):
+    A = hostcsr.erdos_renyi(n, 16, seed=42)
+    _, st = check(ctx, A, A)
+    if n > 70_000:
+        assert st["rows_hash"] > 0
+
+
+def test_rmat_default_paths(ctx):
+    A = hostcsr.rmat(13, 8, seed=1)
+    check(ctx, A, A)
+
+
+def test_rmat_forced_hash_and_global(ctx):
+    A = hostcsr.rmat(12, 8, seed=2)
+    ctx.set_option("window_max_span", 0)
+    try:
+        _, st = check(ctx, A, A)
+        assert st["rows_hash"] > 0 and st["rows_global"] > 0 and st["rows_window"] == 0
+    finally:
+        ctx.set_option("window_max_span", 65536)
+
+
+def test_rmat_forced_global_only(ctx):
+    A = hostcsr.rmat(10, 8, seed=3)
+    ctx.set_option("window_max_span", 0)
+    ctx.set_option("hash_max_nprod", 0)
+    try:
+        _, st = check(ctx, A, A)
+        assert st["rows_global"] > 0 and st["rows_hash"] == 0
+    finally:
+        ctx.set_option("window_max_span", 65536)
+        ctx.set_option("hash_max_nprod", 4096)
+
+
+def test_shell_like_small(ctx):
+    A = hostcsr.shell_like(n_nodes=3000, grid_w=50)
+    _, st = check(ctx, A, A)
+    assert st["rows_window"] == A.rows
+
+
+def test_exact_cancellation_is_dropped(ctx):
+    # row 0 of A*B: column 0 gets 1*1 + 1*(-1) = 0 exactly -> erased; column 1 survives.
+    A = hostcsr.HostCsr.from_coo(3, 2, [0, 0, 1, 2], [0, 1, 0, 1], [1.0, 1.0, 2.0, 3.0])
+    B = hostcsr.HostCsr.from_coo(2, 3, [0, 0, 1, 1, 1], [0, 1, 0, 1, 2], [1.0, 1.0, -1.0, 5.0, 0.25])
+    C, st = check(ctx, A, B)
+    assert st["nnz_structural"] == C.nnz + 1
+    # a larger case: B = [M ; -M] and A = [I I] cancel everything, plus a surviving diagonal
+    n = 700
+    M = hostcsr.banded_random(n, 5, 20, seed=11)
+    r = M.row_ids()
+    Br = np.concatenate([r, r + n, np.arange(n) + 2 * n])
+    Bc = np.concatenate([M.col_idx, M.col_idx, np.arange(n)]).astype(np.int64)
+    Bv = np.concatenate([M.val, -M.val, np.full(n, 2.0)])
+    Bm = hostcsr.HostCsr.from_coo(3 * n, n, Br, Bc, Bv)
+    Ar = np.tile(np.arange(n), 3)
+    Ac = np.concatenate([np.arange(n), np.arange(n) + n, np.arange(n) + 2 * n])
+    Am = hostcsr.HostCsr.from_coo(n, 3 * n, Ar, Ac, np.ones(3 * n))
+    C, st = check(ctx, Am, Bm)
+    assert C.nnz == n and st["nnz_structural"] > n
+
+
+def test_empty_and_ragged(ctx):
+    # no entries at all
+    Z = hostcsr.HostCsr(5, 5, np.zeros(6, dtype=np.uint64), np.zeros(0, dtype=np.uint32), np.zeros(0))
+    C, st = check(ctx, Z, Z)
+    assert C.nnz == 0
+    # empty rows in A, empty rows in B, a dense row, a single column
+    n = 300
+    r = np.concatenate([np.full(n, 7), np.arange(0, n, 3)])
+    c = np.concatenate([np.arange(n), np.full(len(np.arange(0, n, 3)), 5)])
+    v = np.arange(1, len(r) + 1, dtype=np.float64)
+    A = hostcsr.HostCsr.from_coo(n, n, r, c, v)
+    check(ctx, A, A)
+    # rectangular
+    A = hostcsr.HostCsr.from_coo(2, 3, [1, 0, 1], [0, 1, 2], [4.0, 2.0, 6.0])
+    B = hostcsr.HostCsr.from_coo(3, 1, [0, 2], [0, 0], [1.0, -1.0])
+    check(ctx, A, B)
+
+
+def test_unsorted_input_rows_keep_cpu_order(ctx):
+    # rows stored in descending column order: the k order differs from the sorted one and the
+    # result must still follow the storage order bit for bit
+    n = 2000
+    M = hostcsr.banded_random(n, 12, 60, seed=5)
+    rid = M.row_ids()
+    order = np.lexsort((-M.col_idx.astype(np.int64), rid))
+    A = hostcsr.HostCsr(n, n, M.row_ptr, M.col_idx[order], M.val[order])
+    check(ctx, A, A)
+
+
+def test_invalid_inputs_are_rejected(ctx):
+    with pytest.raises(capi.SpgemmError):
+        ctx.from_host(2, 2, np.array([0, 1, 2], dtype=np.uint64), np.array([0, 5], dtype=np.uint32), np.ones(2))
+    A = hostcsr.HostCsr.from_coo(2, 3, [0], [0], [1.0])
+    dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    with pytest.raises(capi.SpgemmError):
+        ctx.multiply(dA, dA)  # 2x3 times 2x3
+    dA.free()
+
+
+def test_section_bitmap_matches_oracle(ctx, golden_dir):
+    A = hostcsr.read_mtx(f"{golden_dir}/ref_first/A.mtx")
+    for P in (2, 4):
+        parts = capi.partition_naive(A.rows, A.cols, P)
+        for (r0, r1, _, _) in parts:
+            blk = to_ocsr(A).select_rows(np.arange(r0, r1))
+            d = ctx.from_host(blk.rows, blk.cols, blk.row_ptr, blk.col_idx, blk.val)
+            assert np.array_equal(ctx.section_bitmap(d, 4), orc.section_bitmap(blk, 4))
+            d.free()
+    big = hostcsr.erdos_renyi(5000, 4, seed=9)
+    blk = to_ocsr(big).select_rows(np.arange(100, 160))
+    d = ctx.from_host(blk.rows, blk.cols, blk.row_ptr, blk.col_idx, blk.val)
+    assert np.array_equal(ctx.section_bitmap(d, 512), orc.section_bitmap(blk, 512))
+    with pytest.raises(capi.SpgemmError):
+        ctx.section_bitmap(d, 4096 * 2)
+    d.free()
