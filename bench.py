@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the SpGEMM hot path: C = A * A, fp64, on N MI355X GPUs of one node.
+
+One step = one full multiply (row analysis, symbolic pass, row-pointer scan, numeric pass and,
+for N > 1, the exchange of the B row sections) with A already resident in HBM.
+Prints ONE JSON line (rank 0).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workloads (synthetic; there is no network to fetch SuiteSparse files):
+  shell  stand-in for Schenk_AFE/af_shell10: same order (1,508,065) and ~35 entries per row
+  er     Erdos-Renyi, n rows, 16 draws per row
+  rmat   R-MAT (0.57, 0.19, 0.19, 0.05), 2^scale rows, edge factor 4
+  mtx    a Matrix Market file given with --matrix (e.g. the real af_shell10)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec); measured float4-copy rate is ~6290 GB/s
+
+
+def make_workload(args):
+    from spgemm_amd import hostcsr
+    if args.workload == "shell":
+        A = hostcsr.shell_like()
+        name = "af_shell10-like synthetic shell (n=1508065, ~35 nnz/row), C=A*A"
+    elif args.workload == "er":
+        A = hostcsr.erdos_renyi(args.n, 16, seed=42)
+        name = f"Erdos-Renyi n={args.n}, 16 draws/row, C=A*A"
+    elif args.workload == "rmat":
+        A = hostcsr.rmat(args.scale, args.edge_factor, seed=1)
+        name = f"R-MAT scale {args.scale}, edge factor {args.edge_factor}, C=A*A"
+    elif args.workload == "mtx":
+        A = hostcsr.read_mtx(args.matrix, eliminate_zeros=True)
+        name = f"{os.path.basename(args.matrix)} C=A*A"
+    else:
+        raise SystemExit(f"unknown workload {args.workload}")
+    return A, name
+
+
+def algorithmic_bytes(nnz_a, nprod, nnz_c, rows):
+    """Row-wise Gustavson traffic model: every A entry, every product's B entry and every C
+    entry moves once as {u32 index, f64 value}; plus the A (u32) and C (u64) row pointers."""
+    return 12 * (nnz_a + nprod + nnz_c) + 4 * (rows + 1) + 8 * (rows + 1)
+
+
+def cpu_baseline(A, target_seconds=12.0):
+    """Times the CPU oracle (a port of the reference's DropParallel loop: one map per output row,
+    OpenMP over rows) on a bounded sample of the same workload: a block of rows of A times all
+    of A.  Checker code used as a baseline; it is not part of the product path."""
+    from oracle import oracle as orc
+    cores = min(orc.lib().oracle_max_threads(), 16)
+    full = orc.OCsr(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    probe_rows = min(A.rows, 20000)
+    start = (A.rows - probe_rows) // 2
+    sub = full.select_rows(np.arange(start, start + probe_rows))
+    _, st = orc.spgemm(sub, full, with_stats=True, nthreads=cores)
+    rate = st["nprod"] / max(st["seconds"], 1e-9)  # products / s
+    prod_per_row = max(st["nprod"] / probe_rows, 1.0)
+    rows = int(min(A.rows, max(probe_rows, target_seconds * rate / prod_per_row)))
+    start = (A.rows - rows) // 2
+    sub = full.select_rows(np.arange(start, start + rows))
+    _, st = orc.spgemm(sub, full, with_stats=True, nthreads=cores)
+    gflops = 2.0 * st["nprod"] / st["seconds"] / 1e9
+    return {"value": gflops, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"rows [{start}, {start + rows}) of A times all of A: {st['nprod']} products "
+                      f"in {st['seconds']:.2f} s (accumulate loop only, as the reference times it)"}
+
+
+def run_single(args):
+    import torch  # device selection / presence check only
+    from spgemm_amd import capi
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    A, name = make_workload(args)
+    ctx = capi.Context(0)
+    dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    ctx.set_option("profile_launches", 1)
+    for _ in range(args.warmup):
+        ctx.multiply(dA, dA).free()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    per_launch_ms = None
+    phase_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        C = ctx.multiply(dA, dA)
+        C.free()
+        st = ctx.stats()
+        ls = ctx.launches()
+        ms = np.array([l["ms"] for l in ls])
+        per_launch_ms = ms if per_launch_ms is None else per_launch_ms + ms
+        for k in ("ms_analyze", "ms_symbolic", "ms_scan", "ms_numeric", "ms_compact", "ms_total"):
+            phase_ms[k] = phase_ms.get(k, 0.0) + st[k]
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ms_per_step = (t1 - t0) * 1e3 / args.steps
+    per_launch_ms = per_launch_ms / args.steps
+    phase_ms = {k: v / args.steps for k, v in phase_ms.items()}
+
+    # one untimed multiply that also sums the rows of every launch (bytes per launch)
+    ctx.set_option("profile_launches", 2)
+    ctx.multiply(dA, dA).free()
+    launches = ctx.launches()
+    st = ctx.stats()
+    for l, ms in zip(launches, per_launch_ms):
+        l["ms"] = float(ms)
+    num = [l for l in launches if l["phase"] == "numeric"]
+    dom = max(num, key=lambda l: l["ms"]) if num else None
+    roofline = None
+    if dom:
+        b = algorithmic_bytes(dom["nnz_a"], dom["nprod"], dom["nnz_c"], dom["rows"])
+        achieved = b / (dom["ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": f"k_num_{dom['path']}<{dom['lanes']}>", "kernel_ms": dom["ms"],
+                    "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b}
+    b_all = st["bytes_algorithmic"]
+    gflops = 2.0 * st["nprod"] / (ms_per_step * 1e-3) / 1e9
+    out = {
+        "metric": "SpGEMM GFLOP/s (useful flops, 2*nprod/t) C=A*A fp64",
+        "value": gflops, "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic" if args.workload != "mtx" else "file",
+        "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": st["nprod"], "nnz_c": st["nnz_c"],
+                   "impl": "baseline", "parallelism": "1 GPU"},
+        "roofline": roofline,
+        "whole_multiply": {"algorithmic_bytes": b_all, "achieved_GBs": b_all / (ms_per_step * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": b_all / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "phase_ms": phase_ms},
+        "launches": [{k: l[k] for k in ("phase", "path", "lanes", "rows", "ms", "lds_bytes", "nprod", "nnz_c")}
+                     for l in launches],
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(A)
+    dA.free()
+    ctx.close()
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="shell", choices=["shell", "er", "rmat", "mtx"])
+    ap.add_argument("--n", type=int, default=1 << 22, help="rows of the Erdos-Renyi workload")
+    ap.add_argument("--scale", type=int, default=22, help="log2 rows of the R-MAT workload")
+    ap.add_argument("--edge-factor", type=int, default=4)
+    ap.add_argument("--matrix", default=None, help="Matrix Market file for --workload mtx")
+    ap.add_argument("--impl", default="drop", choices=["baseline", "drop", "shuffle"],
+                    help="distributed variant (N > 1): all sections, bitmap-filtered sections, "
+                         "or random row/column shuffle + bitmap")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus == 1 and world == 1:
+        run_single(args)
+    else:
+        from spgemm_amd import dist
+        dist.bench_main(args)
+
+
+if __name__ == "__main__":
+    main()

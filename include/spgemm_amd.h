@@ -122,6 +122,26 @@ int spgemm_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B,
                    uint64_t *d_row_ptr, uint32_t *d_col_idx, double *d_val, uint64_t *nnz_final);
 int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out);
 
+/* Per-launch figures of the last multiply, filled only when the option "profile_launches" is
+ * 1 (each symbolic / numeric kernel launch is bracketed by HIP events on the context's stream:
+ * `ms` is valid) or 2 (additionally the rows each launch worked on are summed up: nnz_a, nprod
+ * and nnz_c are valid; this adds small kernels and host syncs to the multiply).  No counterpart in the reference, whose
+ * measure points are per phase (include/measure.hpp:16-30). */
+typedef struct spgemm_launch_info {
+  uint32_t phase;  /* 0 symbolic, 1 numeric */
+  uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch */
+  uint32_t lanes;  /* lanes per A entry (symbolic) or per row (numeric) */
+  uint32_t rows;   /* rows handled by the launch */
+  uint32_t param0; /* window: bitmap words; hash: log2 of the table size */
+  uint32_t param1; /* window numeric: value slots */
+  float ms;        /* device time of the launch */
+  uint32_t lds_bytes; /* dynamic LDS per workgroup */
+  uint64_t nnz_a;  /* A entries of those rows */
+  uint64_t nprod;  /* products of those rows */
+  uint64_t nnz_c;  /* structural output entries of those rows */
+} spgemm_launch_info;
+int spgemm_get_launches(spgemm_ctx *ctx, spgemm_launch_info *out, int max_out, int *count);
+
 /* ---- section bitmap: replaces bitmap::compute_bitmap (src/bitmap.cpp:12-40).
  *      bit s = min(col / (A.cols / n_sections), n_sections - 1); words_out is a HOST array of
  *      ceil(n_sections / 64) words.  Fails with SPGEMM_ERR_INVALID when A.cols / n_sections

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "spgemm_create", "spgemm_destroy", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option",
     "spgemm_mat_from_host", "spgemm_mat_wrap_device", "spgemm_mat_info", "spgemm_mat_device_ptrs",
     "spgemm_mat_to_host", "spgemm_mat_free",
-    "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats",
+    "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
     "spgemm_section_bitmap",
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
     "spgemm_shuffle_random", "spgemm_mat_select",
@@ -54,6 +54,19 @@ class Stats(ctypes.Structure):
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class LaunchInfo(ctypes.Structure):
+    _fields_ = [("phase", ctypes.c_uint32), ("path", ctypes.c_uint32), ("lanes", ctypes.c_uint32),
+                ("rows", ctypes.c_uint32), ("param0", ctypes.c_uint32), ("param1", ctypes.c_uint32),
+                ("ms", ctypes.c_float), ("lds_bytes", ctypes.c_uint32),
+                ("nnz_a", ctypes.c_uint64), ("nprod", ctypes.c_uint64), ("nnz_c", ctypes.c_uint64)]
+
+    def as_dict(self) -> dict:
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["phase"] = ("symbolic", "numeric")[d["phase"]]
+        d["path"] = ("window", "hash", "global")[d["path"]]
+        return d
 
 
 _lib: Optional[ctypes.CDLL] = None
@@ -90,6 +103,7 @@ def load() -> ctypes.CDLL:
         "spgemm_symbolic": (i32, [vp, vp, vp, vp, ctypes.POINTER(u64)]),
         "spgemm_numeric": (i32, [vp, vp, vp, vp, vp, vp, ctypes.POINTER(u64)]),
         "spgemm_get_stats": (i32, [vp, ctypes.POINTER(Stats)]),
+        "spgemm_get_launches": (i32, [vp, ctypes.POINTER(LaunchInfo), i32, ctypes.POINTER(i32)]),
         "spgemm_section_bitmap": (i32, [vp, vp, u32, vp]),
         "spgemm_partition_naive": (i32, [u32, u32, i32, ctypes.POINTER(Partition)]),
         "spgemm_partition_balanced": (i32, [vp, u32, u32, i32, ctypes.POINTER(Partition)]),
@@ -261,6 +275,14 @@ class Context:
         s = Stats()
         _check(load().spgemm_get_stats(self.handle, ctypes.byref(s)))
         return s.as_dict()
+
+    def launches(self) -> list:
+        """Per-launch figures of the last multiply (needs set_option("profile_launches", 1))."""
+        n = ctypes.c_int(0)
+        _check(load().spgemm_get_launches(self.handle, None, 0, ctypes.byref(n)))
+        arr = (LaunchInfo * max(n.value, 1))()
+        _check(load().spgemm_get_launches(self.handle, arr, n.value, ctypes.byref(n)))
+        return [arr[i].as_dict() for i in range(n.value)]
 
     # -- bitmap / partition / shuffle ------------------------------------------------------------
     def section_bitmap(self, A: DeviceCsr, n_sections: int) -> np.ndarray:

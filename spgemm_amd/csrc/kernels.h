@@ -167,13 +167,14 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
 // ---- A row analysis --------------------------------------------------------------------------
 // Per A row: nprod = sum of B row lengths, [cmin, cmax] = hull of the B rows' column ranges,
 // the symbolic bin key and the upper bound `ub` on the row's distinct columns.
+constexpr uint32_t NPROD_SLOTS = 256;
 struct AnalyzeOut {
   uint32_t *r_cmin;
   uint32_t *r_cmax;
   uint32_t *r_ub;
   uint8_t *r_key;
   uint64_t *r_nprod;       // optional (may be null)
-  uint64_t *total_nprod;   // single counter
+  uint64_t *total_nprod;   // NPROD_SLOTS partial counters, summed by the host
   uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
   uint32_t *long_count;
 };
@@ -231,9 +232,16 @@ __global__ void __launch_bounds__(256)
       contrib = np;
     }
   }
-  // one atomic per wavefront for the product total
+  // product total: reduce over the workgroup, then one atomic per workgroup, spread over
+  // NPROD_SLOTS counters (atomics on a single word would serialise the whole grid)
+  __shared__ uint64_t s_c[4];
   contrib = group_sum64<64>(contrib);
-  if ((threadIdx.x & 63) == 0 && contrib) atomicAdd((unsigned long long *)o.total_nprod, (unsigned long long)contrib);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd((unsigned long long *)&o.total_nprod[blockIdx.x & (NPROD_SLOTS - 1)], (unsigned long long)t);
+  }
 }
 
 // One 256-thread workgroup per long A row.
@@ -271,7 +279,7 @@ __global__ void __launch_bounds__(256)
       mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
       mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
       analyze_finish(row, np, mn, mx, (uint32_t)(a1 - a0), o, cp);
-      if (np) atomicAdd((unsigned long long *)o.total_nprod, (unsigned long long)np);
+      if (np) atomicAdd((unsigned long long *)&o.total_nprod[blockIdx.x & (NPROD_SLOTS - 1)], (unsigned long long)np);
     }
     __syncthreads();
   }
@@ -457,10 +465,57 @@ struct RowMeta {
   uint8_t *__restrict__ num_key;      // numeric bin key per row
 };
 
-// ---- symbolic, window path: one wavefront per row, LPK lanes per A entry -----------------------
+// ---- walking the products of one row ----------------------------------------------------------
+// Wave-uniform broadcast of a 64-bit lane value (index uniform across the wavefront).
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
+  return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), l));
+}
+
+constexpr int PF = 4; // B rows whose first 64 entries are fetched before any of them is consumed
+
+// Order-free walk (symbolic): the whole wavefront takes one A entry at a time, lanes over the B
+// row; the loads of PF consecutive B rows are issued back to back so their latencies overlap.
+template <class F>
+__device__ __forceinline__ void wave_for_each_col(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
+  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+  for (uint64_t ab = a0; ab < a1; ab += 64) {
+    const uint64_t ka = ab + lane;
+    uint64_t b0 = 0, b1 = 0;
+    if (ka < a1) {
+      uint32_t k = A.col[ka];
+      b0 = B.ptr[k];
+      b1 = B.ptr[k + 1];
+    }
+    const uint32_t cnt = (uint32_t)min((uint64_t)64, a1 - ab);
+    for (uint32_t t = 0; t < cnt; t += PF) {
+      uint32_t c[PF];
+      uint64_t s[PF], e[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const uint32_t tt = min(t + u, 63u);
+        s[u] = readlane64(b0, tt);
+        e[u] = (t + u < cnt) ? readlane64(b1, tt) : s[u];
+        const uint64_t j = s[u] + lane;
+        c[u] = (j < e[u]) ? B.col[j] : EMPTY_KEY;
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (c[u] != EMPTY_KEY) f(c[u]);
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (e[u] - s[u] > 64)
+          for (uint64_t j = s[u] + 64 + lane; j < e[u]; j += 64) f(B.col[j]);
+    }
+  }
+}
+
+// ---- symbolic, window path: one wavefront per row ------------------------------------------------
 // LDS per wavefront: `words` uint32 bitmap words covering columns [cmin & ~31, cmax].
-// Order-free (bit OR), so the A entries are spread over 64/LPK sub-groups.
-template <int LPK>
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                  uint32_t words) {
@@ -474,17 +529,10 @@ __global__ void __launch_bounds__(256)
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
   for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
   lds_fence();
-  constexpr uint32_t NSG = 64 / LPK;
-  const uint32_t sg = lane / LPK, sl = lane % LPK;
-  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
-  for (uint64_t ka = a0 + sg; ka < a1; ka += NSG) {
-    uint32_t k = A.col[ka];
-    uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-    for (uint64_t jb = b0 + sl; jb < b1; jb += LPK) {
-      uint32_t c = B.col[jb] - base;
-      atomicOr(&bm[c >> 5], 1u << (c & 31u));
-    }
-  }
+  wave_for_each_col(A, B, row, lane, [&](uint32_t col) {
+    uint32_t c = col - base;
+    atomicOr(&bm[c >> 5], 1u << (c & 31u));
+  });
   lds_fence();
   // enumerate set bits in ascending order -> sorted structural columns
   uint32_t *out = m.temp_cols + m.t_off[row];
@@ -514,7 +562,6 @@ __global__ void __launch_bounds__(256)
 // S >= 2 * nprod, so the table is at most half full.  Sorting is a bucket rank sort: a monotone
 // map of the column into S/2 buckets, counting sort into bucket order, then each key finds its
 // rank among the (few) keys of its bucket.
-template <int LPK>
 __global__ void __launch_bounds__(256)
     k_sym_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                uint32_t log2s) {
@@ -530,24 +577,16 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
   for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
   lds_fence();
-  constexpr uint32_t NSG = 64 / LPK;
-  const uint32_t sg = lane / LPK, sl = lane % LPK;
-  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
   uint32_t mine = 0;
-  for (uint64_t ka = a0 + sg; ka < a1; ka += NSG) {
-    uint32_t k = A.col[ka];
-    uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-    for (uint64_t jb = b0 + sl; jb < b1; jb += LPK) {
-      uint32_t c = B.col[jb];
-      uint32_t h = hash_slot(c, log2s);
-      for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
-        uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
-        if (old == EMPTY_KEY) { ++mine; break; }
-        if (old == c) break;
-        h = (h + 1u) & mask;
-      }
+  wave_for_each_col(A, B, row, lane, [&](uint32_t c) {
+    uint32_t h = hash_slot(c, log2s);
+    for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+      uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+      if (old == EMPTY_KEY) { ++mine; break; }
+      if (old == c) break;
+      h = (h + 1u) & mask;
     }
-  }
+  });
   lds_fence();
   const uint32_t n = group_sum<64>(mine);
   const uint32_t cmin = m.cmin[row];
@@ -656,30 +695,51 @@ struct NumOut {
 };
 
 // Walk the products of `row` in the CPU order and call acc(col, product).
-// The group preloads G A entries (column, value, B row bounds) at a time, then visits them one
-// by one; for one A entry the G lanes take consecutive entries of the B row.
+// The group preloads G A entries (value, B row bounds) at a time, then visits them one by one;
+// for one A entry the G lanes take consecutive entries of the B row.  The first G entries of PF
+// consecutive B rows are fetched back to back (their latencies overlap) and consumed strictly in
+// A order, each B row completely before the next one.
 template <int G, class F>
 __device__ __forceinline__ void for_each_product(const Csr &A, const Csr &B, uint32_t row, uint32_t lg, F acc) {
   const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
   for (uint64_t ab = a0; ab < a1; ab += G) {
     uint64_t ka = ab + lg;
-    uint32_t k = 0;
     double av = 0.0;
     uint64_t b0 = 0, b1 = 0;
     if (ka < a1) {
-      k = A.col[ka];
+      uint32_t k = A.col[ka];
       av = A.val[ka];
       b0 = B.ptr[k];
       b1 = B.ptr[k + 1];
     }
     const uint32_t cnt = (uint32_t)min((uint64_t)G, a1 - ab);
-    for (uint32_t t = 0; t < cnt; ++t) {
-      const double avt = __shfl(av, t, G);
-      const uint64_t b0t = __shfl(b0, t, G), b1t = __shfl(b1, t, G);
-      for (uint64_t jb = b0t + lg; jb < b1t; jb += G) {
-        uint32_t c = B.col[jb];
-        double p = __dmul_rn(avt, B.val[jb]);
-        acc(c, p);
+    for (uint32_t t = 0; t < cnt; t += PF) {
+      uint32_t c[PF];
+      double v[PF], avt[PF];
+      uint64_t s[PF], e[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const uint32_t tt = min(t + u, (uint32_t)(G - 1));
+        if constexpr (G == 64) {
+          s[u] = readlane64(b0, tt);
+          e[u] = readlane64(b1, tt);
+          avt[u] = readlane_f64(av, tt);
+        } else {
+          s[u] = __shfl(b0, tt, G);
+          e[u] = __shfl(b1, tt, G);
+          avt[u] = __shfl(av, tt, G);
+        }
+        if (t + u >= cnt) e[u] = s[u];
+        const uint64_t j = s[u] + lg;
+        const bool ok = j < e[u];
+        c[u] = ok ? B.col[j] : EMPTY_KEY;
+        v[u] = ok ? B.val[j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (c[u] != EMPTY_KEY) acc(c[u], __dmul_rn(avt[u], v[u]));
+        if (e[u] - s[u] > G)
+          for (uint64_t j = s[u] + G + lg; j < e[u]; j += G) acc(B.col[j], __dmul_rn(avt[u], B.val[j]));
       }
     }
   }
@@ -901,6 +961,28 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x)
     if (s_bits[i]) atomicOr(&words[i], s_bits[i]);
+}
+
+// ---- per-launch accounting (profile mode): sums over the rows of one bin --------------------------
+__global__ void __launch_bounds__(256)
+    k_bin_sums(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
+               const uint64_t *__restrict__ r_nprod, const uint32_t *__restrict__ r_nnz,
+               unsigned long long *__restrict__ out /* nnz_a, nprod, nnz_c */) {
+  uint64_t sa = 0, sp = 0, sc = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
+    uint32_t r = rows[i];
+    sa += a_ptr[r + 1] - a_ptr[r];
+    sp += r_nprod[r];
+    sc += r_nnz[r];
+  }
+  sa = group_sum64<64>(sa);
+  sp = group_sum64<64>(sp);
+  sc = group_sum64<64>(sc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)sa);
+    atomicAdd(&out[1], (unsigned long long)sp);
+    atomicAdd(&out[2], (unsigned long long)sc);
+  }
 }
 
 // ---- validation ------------------------------------------------------------------------------

@@ -85,6 +85,16 @@ struct spgemm_ctx {
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
   size_t pool_bytes = 0;
   spgemm_stats stats;
+  // per-launch profile (option "profile_launches")
+  int profile = 0; // 0 off, 1 per-launch events, 2 events + per-launch row sums
+  std::vector<hipEvent_t> prof_events;
+  struct LaunchRec {
+    spgemm_launch_info info;
+    const uint32_t *rows_bin;
+    int ev0, ev1;
+  };
+  std::vector<LaunchRec> launches;
+  uint64_t *r_nprod_prof = nullptr;
   // state carried from spgemm_symbolic to spgemm_numeric
   struct Plan {
     bool valid = false;
@@ -248,10 +258,8 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() {
   if (g_attr_set) return;
-  raise_lds_limit(k_sym_window<8>); raise_lds_limit(k_sym_window<16>);
-  raise_lds_limit(k_sym_window<32>); raise_lds_limit(k_sym_window<64>);
-  raise_lds_limit(k_sym_hash<8>); raise_lds_limit(k_sym_hash<16>);
-  raise_lds_limit(k_sym_hash<32>); raise_lds_limit(k_sym_hash<64>);
+  raise_lds_limit(k_sym_window);
+  raise_lds_limit(k_sym_hash);
   raise_lds_limit(k_num_window<8>); raise_lds_limit(k_num_window<16>);
   raise_lds_limit(k_num_window<32>); raise_lds_limit(k_num_window<64>);
   raise_lds_limit(k_num_hash<8>); raise_lds_limit(k_num_hash<16>);
@@ -333,6 +341,7 @@ extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   if (ctx->d_small) (void)hipFree(ctx->d_small);
   for (auto &ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return SPGEMM_OK;
@@ -375,6 +384,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "lds_budget") {
     if (value < 8192 || value > 160 * 1024) return fail(SPGEMM_ERR_INVALID, "lds_budget must be 8192..163840");
     ctx->lds_budget = (size_t)value;
+  } else if (n == "profile_launches") {
+    if (value > 2) return fail(SPGEMM_ERR_INVALID, "profile_launches is 0, 1 or 2");
+    ctx->profile = (int)value;
   } else if (n == "global_blocks_sym") {
     if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "global_blocks_sym must be 1..4096");
     ctx->global_blocks_sym = (uint32_t)value;
@@ -510,6 +522,51 @@ extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
   return SPGEMM_OK;
 }
 
+// ---- per-launch profile ----------------------------------------------------------------------------
+static int prof_begin(spgemm_ctx *ctx, uint32_t phase, uint32_t path, uint32_t lanes, uint32_t rows, uint32_t p0,
+                      uint32_t p1, size_t lds, const uint32_t *rows_bin) {
+  if (!ctx->profile) return SPGEMM_OK;
+  size_t need = (ctx->launches.size() + 1) * 2;
+  while (ctx->prof_events.size() < need) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    ctx->prof_events.push_back(e);
+  }
+  spgemm_ctx::LaunchRec r;
+  memset(&r.info, 0, sizeof(r.info));
+  r.info.phase = phase; r.info.path = path; r.info.lanes = lanes; r.info.rows = rows;
+  r.info.param0 = p0; r.info.param1 = p1; r.info.lds_bytes = (uint32_t)lds;
+  r.rows_bin = rows_bin;
+  r.ev0 = (int)(ctx->launches.size() * 2);
+  r.ev1 = r.ev0 + 1;
+  ctx->launches.push_back(r);
+  HIP_TRY(hipEventRecord(ctx->prof_events[r.ev0], ctx->stream));
+  return SPGEMM_OK;
+}
+static int prof_end(spgemm_ctx *ctx) {
+  if (!ctx->profile) return SPGEMM_OK;
+  HIP_TRY(hipEventRecord(ctx->prof_events[ctx->launches.back().ev1], ctx->stream));
+  return SPGEMM_OK;
+}
+
+// Sum nnz_a / nprod / nnz_c over the rows of every launch of `phase` (after the phase's events).
+static int prof_collect(spgemm_ctx *ctx, const spgemm_mat *A, const uint32_t *r_nnz, uint32_t phase) {
+  if (ctx->profile < 2) return SPGEMM_OK;
+  for (auto &r : ctx->launches) {
+    if (r.info.phase != phase) continue;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_small) + 8;
+    HIP_TRY(hipMemsetAsync(d, 0, 24, ctx->stream));
+    hipLaunchKernelGGL(k_bin_sums, dim3(std::min<uint32_t>(div_up_u64(r.info.rows, 256), 1024)), dim3(256), 0,
+                       ctx->stream, r.rows_bin, r.info.rows, A->d_ptr, ctx->r_nprod_prof, r_nnz, d);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[3];
+    HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    r.info.nnz_a = h[0]; r.info.nprod = h[1]; r.info.nnz_c = h[2];
+  }
+  return SPGEMM_OK;
+}
+
 // ---- the multiply -------------------------------------------------------------------------------
 struct HostCounts {
   uint64_t bin_off[MAX_BINS + 1];
@@ -517,6 +574,7 @@ struct HostCounts {
   uint64_t total_nprod;
   uint32_t long_count;
   uint32_t pad;
+  uint64_t nprod_parts[NPROD_SLOTS];
 };
 static_assert(sizeof(HostCounts) <= PINNED_BYTES, "pinned staging buffer too small");
 
@@ -529,6 +587,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   if (A->cols != B->rows) return fail(SPGEMM_ERR_INVALID, "A.cols (%llu) != B.rows (%llu)", (unsigned long long)A->cols, (unsigned long long)B->rows);
   if (A->device != ctx->device || B->device != ctx->device) return fail(SPGEMM_ERR_INVALID, "matrix lives on another device");
   ctx->plan.valid = false;
+  ctx->launches.clear();
   const uint32_t rows = (uint32_t)A->rows;
   spgemm_stats &st = ctx->stats;
   memset(&st, 0, sizeof(st));
@@ -549,13 +608,14 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   const uint32_t max_long = (uint32_t)std::min<uint64_t>(rows, A->nnz / (ctx->long_len + 1) + 1);
   size_t need = 0;
   need += 4 * align_up((size_t)rows * 4, 256);            // cmin, cmax, ub, nnz
+  if (ctx->profile >= 2) need += align_up((size_t)rows * 8, 256) + 256 * 64; // per-row products, per-launch sums
   need += 2 * align_up((size_t)rows, 256);                // key, numkey
   need += align_up((size_t)rows * 4, 256);                // perm
   need += align_up(((size_t)rows + 1) * 8, 256);          // t_off
   need += align_up((size_t)max_long * 4, 256) + 256;      // long rows + counter
   need += align_up(hist_n * 4, 256) + align_up((hist_n + 1) * 8, 256); // partition histogram + scan
   need += align_up(((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2) * 8, 256); // scan partials
-  need += align_up((MAX_BINS + 1) * 8, 256) + 256 + 256 + 256; // bin_off, counters
+  need += align_up((MAX_BINS + 1) * 8, 256) + NPROD_SLOTS * 8 + 256 + 256; // bin_off, counters
   TRY(grow(ctx, ctx->arena, need));
   ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
   uint32_t *r_cmin = ar.take<uint32_t>(rows), *r_cmax = ar.take<uint32_t>(rows);
@@ -569,17 +629,20 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint64_t *blk_off = ar.take<uint64_t>(hist_n + 1);
   uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2);
   uint64_t *bin_off = ar.take<uint64_t>(MAX_BINS + 1);
-  uint64_t *total_nprod = ar.take<uint64_t>(32);
+  uint64_t *total_nprod = ar.take<uint64_t>(NPROD_SLOTS);
   unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32));
+  uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
+  ctx->r_nprod_prof = r_nprod;
+  ctx->launches.clear();
   ctx->arena_used = ar.used;
   if (ar.used > ar.cap) return fail(SPGEMM_ERR_STATE, "internal: arena layout exceeds its size");
 
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
-  HIP_TRY(hipMemsetAsync(total_nprod, 0, 256, ctx->stream));
+  HIP_TRY(hipMemsetAsync(total_nprod, 0, NPROD_SLOTS * 8, ctx->stream));
   HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
   HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
 
-  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, nullptr, total_nprod, long_rows, long_count};
+  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   if (max_long > 1 || A->nnz > ctx->long_len)
@@ -593,9 +656,10 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
   HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (SYM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(&hc->total_nprod, total_nprod, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(hc->nprod_parts, total_nprod, NPROD_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  st.nprod = hc->total_nprod;
+  st.nprod = 0;
+  for (uint32_t i = 0; i < NPROD_SLOTS; ++i) st.nprod += hc->nprod_parts[i];
   const uint64_t total_ub = hc->total_a;
   uint64_t boff[SYM_NBINS + 1];
   memcpy(boff, hc->bin_off, sizeof(boff));
@@ -617,18 +681,18 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       size_t region = (size_t)words * 4;
       uint32_t wpb = 4;
       st.rows_window += cnt;
-      Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, uint32_t>::go<k_sym_window<8>, k_sym_window<16>,
-                                                                            k_sym_window<32>, k_sym_window<64>>(
-          gsel, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
+      TRY(prof_begin(ctx, 0, 0, 64, cnt, words, 0, region * wpb, rows_bin));
+      hipLaunchKernelGGL(k_sym_window, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
+                         cnt, cA, cB, rm, words);
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
       uint32_t log2s = 7 + 2 * tier;
       size_t region = (size_t)8 << log2s;
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
       st.rows_hash += cnt;
-      Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, uint32_t>::go<k_sym_hash<8>, k_sym_hash<16>,
-                                                                            k_sym_hash<32>, k_sym_hash<64>>(
-          gsel, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
+      TRY(prof_begin(ctx, 0, 1, 64, cnt, log2s, 0, region * wpb, rows_bin));
+      hipLaunchKernelGGL(k_sym_hash, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
+                         cnt, cA, cB, rm, log2s);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
@@ -638,13 +702,16 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
         HIP_TRY(hipMemsetAsync(ctx->gscratch.p, 0, ctx->gscratch.cap, ctx->stream));
       }
       st.rows_global += cnt;
+      TRY(prof_begin(ctx, 0, 2, 64, cnt, 0, 0, 0, rows_bin));
       hipLaunchKernelGGL(k_sym_global, dim3(blocks), dim3(256), 0, ctx->stream, rows_bin, cnt, cA, cB, rm,
                          reinterpret_cast<uint32_t *>(ctx->gscratch.p), words_total);
     }
     HIP_TRY(hipGetLastError());
+    TRY(prof_end(ctx));
   }
   st.rows_empty = rows - st.rows_window - st.rows_hash - st.rows_global;
   HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+  TRY(prof_collect(ctx, A, r_nnz, 0));
   TRY(launch_scan(ctx, r_nnz, rows, d_row_ptr, partial));
 
   spgemm_ctx::Plan &pl = ctx->plan;
@@ -721,6 +788,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       gpb = std::min<uint32_t>(gpb, 256 / G);
       dim3 grid(div_up_u64(cnt, gpb)), block(threads_for(gpb, G));
       size_t lds = (size_t)gpb * region;
+      TRY(prof_begin(ctx, 1, window ? 0 : 1, G, cnt, p0, p1, lds, rows_bin));
       if (window) {
         Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, NumOut, uint32_t, uint32_t, uint32_t>::go<
             k_num_window<8>, k_num_window<16>, k_num_window<32>, k_num_window<64>>(gsel, grid, block, lds, ctx->stream,
@@ -738,12 +806,15 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
         TRY(grow(ctx, ctx->gscratch, bytes));
         HIP_TRY(hipMemsetAsync(ctx->gscratch.p, 0, ctx->gscratch.cap, ctx->stream));
       }
+      TRY(prof_begin(ctx, 1, 2, 64, cnt, 0, 0, 0, rows_bin));
       hipLaunchKernelGGL(k_num_global, dim3(blocks), dim3(64), 0, ctx->stream, rows_bin, cnt, cA, cB, rm, no,
                          reinterpret_cast<unsigned long long *>(ctx->gscratch.p), words_total);
     }
     HIP_TRY(hipGetLastError());
+    TRY(prof_end(ctx));
   }
   HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+  TRY(prof_collect(ctx, A, pl.r_nnz, 1));
   HIP_TRY(hipMemcpyAsync(&hc->total_a, zero_count, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   uint64_t zeros = hc->total_a;
@@ -799,6 +870,10 @@ static int finish_stats(spgemm_ctx *ctx, uint64_t rows_c, uint64_t nnz_final) {
   HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); st.ms_numeric = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); st.ms_compact = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[5])); st.ms_total = ms;
+  for (auto &r : ctx->launches) {
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[r.ev0], ctx->prof_events[r.ev1]));
+    r.info.ms = ms;
+  }
   st.nnz_c = nnz_final;
   st.bytes_algorithmic = 12ull * (st.nnz_a + st.nprod + st.nnz_c) + 4ull * (st.rows_a + 1) + 8ull * (rows_c + 1);
   st.temp_bytes = ctx->arena.cap + ctx->temp_cols.cap + ctx->gscratch.cap;
@@ -862,6 +937,15 @@ extern "C" int spgemm_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm
   TRY(finish_stats(ctx, A->rows, nnz_f));
   ctx->plan.valid = false;
   *nnz_final = nnz_f;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_get_launches(spgemm_ctx *ctx, spgemm_launch_info *out, int max_out, int *count) {
+  if (!ctx || !count) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  int n = (int)ctx->launches.size();
+  *count = n;
+  if (out)
+    for (int i = 0; i < n && i < max_out; ++i) out[i] = ctx->launches[i].info;
   return SPGEMM_OK;
 }
 
@@ -940,7 +1024,7 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   if (!rows) return SPGEMM_OK;
   TRY(ensure_rowinfo(ctx, B));
   ctx->plan.valid = false;
-  size_t need = 3 * align_up((size_t)rows * 4, 256) + align_up(rows, 256) + align_up((size_t)rows * 8, 256) + 1024;
+  size_t need = 3 * align_up((size_t)rows * 4, 256) + align_up(rows, 256) + align_up((size_t)rows * 8, 256) + 1024 + NPROD_SLOTS * 8;
   const uint32_t max_long = rows;
   need += align_up((size_t)max_long * 4, 256);
   TRY(grow(ctx, ctx->arena, need));
@@ -950,9 +1034,9 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   uint64_t *np = ar.take<uint64_t>(rows);
   uint32_t *long_rows = ar.take<uint32_t>(max_long);
   uint32_t *long_count = ar.take<uint32_t>(64);
-  uint64_t *total = ar.take<uint64_t>(32);
+  uint64_t *total = ar.take<uint64_t>(NPROD_SLOTS);
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
-  HIP_TRY(hipMemsetAsync(total, 0, 256, ctx->stream));
+  HIP_TRY(hipMemsetAsync(total, 0, NPROD_SLOTS * 8, ctx->stream));
   AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
