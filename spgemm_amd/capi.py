@@ -13,7 +13,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspgemm_amd.so")
+# SPGEMM_AMD_LIB: path of an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("SPGEMM_AMD_LIB") or os.path.join(_HERE, "libspgemm_amd.so")
 
 # every symbol include/spgemm_amd.h declares
 EXPORTED_SYMBOLS = [

@@ -91,14 +91,35 @@ __device__ __forceinline__ void lds_fence() {
   asm volatile("" ::: "memory");
 }
 
+// Data-parallel-primitive lane shifts (VALU only, no LDS traffic).  row_shr:n moves a value n
+// lanes up inside each 16-lane row; lanes without a source get `fill`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t fill, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// Inclusive add-scan inside groups of W consecutive lanes (W = 8, 16, 32 or 64).
 template <int W> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v) {
-  const int l = threadIdx.x & (W - 1);
-#pragma unroll
-  for (int d = 1; d < W; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, W);
-    if (l >= d) v += t;
+  uint32_t t;
+  if constexpr (W == 8) {
+    const uint32_t l = threadIdx.x & 7u;
+    t = dpp_move<0x111>(0u, v); if (l >= 1) v += t;
+    t = dpp_move<0x112>(0u, v); if (l >= 2) v += t;
+    t = dpp_move<0x114>(0u, v); if (l >= 4) v += t;
+  } else {
+    v += dpp_move<0x111>(0u, v);
+    v += dpp_move<0x112>(0u, v);
+    v += dpp_move<0x114>(0u, v);
+    v += dpp_move<0x118>(0u, v);
+    if constexpr (W >= 32) v += dpp_move<0x142, 0xA>(0u, v); // row_bcast:15 into rows 1 and 3
+    if constexpr (W >= 64) v += dpp_move<0x143, 0xC>(0u, v); // row_bcast:31 into rows 2 and 3
   }
   return v;
+}
+// value of the last lane of the group
+template <int W> __device__ __forceinline__ uint32_t group_last(uint32_t v) {
+  if constexpr (W == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  else return __shfl(v, W - 1, W);
 }
 template <int W> __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
 #pragma unroll
@@ -476,7 +497,87 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
   return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), l));
 }
 
-constexpr int PF = 4; // B rows whose first 64 entries are fetched before any of them is consumed
+#ifndef SG_PF
+#define SG_PF 4
+#endif
+#ifndef SG_SYM_COMBINE
+#define SG_SYM_COMBINE 1
+#endif
+#ifndef SG_SYM_ENUM_SEARCH
+#define SG_SYM_ENUM_SEARCH 1
+#endif
+constexpr int PF = SG_PF; // B rows whose first 64 entries are fetched before any of them is consumed
+
+// Wave-per-row walk with the A row handled on the scalar unit.  `row` must be wave-uniform
+// (derived through readfirstlane): the A entries, their values and the bounds of the B rows
+// are then fetched by scalar loads and live in SGPRs, the B row base is a scalar pointer and a
+// lane addresses its entry as base + lane * size, so the vector ALU does no index arithmetic
+// at all.  The first 64 entries of PF consecutive B rows are fetched back to back; each B row
+// is consumed completely, in A order, before the next one (the order of the CPU loop).
+// f(col, bval, aval): bval/aval are only loaded when WITH_VAL.
+// Read-only kernel inputs seen through the constant address space: a load whose address is
+// wave-uniform is then issued on the scalar unit (s_load) instead of the vector memory path.
+template <class T> using const_as_ptr = const T __attribute__((address_space(4))) *;
+template <class T> __device__ __forceinline__ const_as_ptr<T> scalar_view(const T *p) {
+  return (const_as_ptr<T>)(uintptr_t)p;
+}
+
+template <bool WITH_VAL, class F>
+__device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
+  const auto a_ptr = scalar_view(A.ptr);
+  const auto a_col = scalar_view(A.col);
+  const auto a_val = scalar_view(A.val);
+  const auto b_ptr = scalar_view(B.ptr);
+  const uint64_t a0 = a_ptr[row], a1 = a_ptr[row + 1];
+  for (uint64_t ka = a0; ka < a1; ka += PF) {
+    uint32_t len[PF], k[PF];
+    const uint32_t *pc[PF];
+    const double *pv[PF];
+    double av[PF];
+    uint64_t p0[PF], p1[PF];
+    // stage 1: PF A entries (independent scalar loads; the last group re-reads the row's last entry)
+    if (ka + PF <= a1) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        k[u] = a_col[ka + u];
+        if constexpr (WITH_VAL) av[u] = a_val[ka + u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const uint64_t kk = min(ka + u, a1 - 1);
+        k[u] = a_col[kk];
+        if constexpr (WITH_VAL) av[u] = a_val[kk];
+      }
+    }
+    // stage 2: bounds of the PF B rows
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      p0[u] = b_ptr[k[u]];
+      p1[u] = b_ptr[k[u] + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      len[u] = (ka + u < a1) ? (uint32_t)(p1[u] - p0[u]) : 0u;
+      pc[u] = B.col + p0[u];
+      pv[u] = B.val + p0[u];
+    }
+    uint32_t c[PF];
+    double v[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const bool ok = lane < len[u];
+      c[u] = ok ? pc[u][lane] : EMPTY_KEY;
+      if constexpr (WITH_VAL) v[u] = ok ? pv[u][lane] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (c[u] != EMPTY_KEY) f(c[u], WITH_VAL ? v[u] : 0.0, WITH_VAL ? av[u] : 0.0);
+      if (len[u] > 64) // wave-uniform
+        for (uint32_t j = 64 + lane; j < len[u]; j += 64) f(pc[u][j], WITH_VAL ? pv[u][j] : 0.0, WITH_VAL ? av[u] : 0.0);
+    }
+  }
+}
 
 // Order-free walk (symbolic): the whole wavefront takes one A entry at a time, lanes over the B
 // row; the loads of PF consecutive B rows are issued back to back so their latencies overlap.
@@ -514,32 +615,50 @@ __device__ __forceinline__ void wave_for_each_col(const Csr &A, const Csr &B, ui
   }
 }
 
+// r-th (0-based) set bit of a 32-bit word that has more than r bits set
+__device__ __forceinline__ uint32_t select_bit(uint32_t bits, uint32_t r) {
+  uint32_t base = 0, c;
+  c = __popc(bits & 0xFFFFu); if (r >= c) { r -= c; bits >>= 16; base += 16; }
+  c = __popc(bits & 0xFFu);   if (r >= c) { r -= c; bits >>= 8;  base += 8; }
+  c = __popc(bits & 0xFu);    if (r >= c) { r -= c; bits >>= 4;  base += 4; }
+  c = __popc(bits & 0x3u);    if (r >= c) { r -= c; bits >>= 2;  base += 2; }
+  c = bits & 1u;              if (r >= c) { base += 1; }
+  return base;
+}
+
 // ---- symbolic, window path: one wavefront per row ------------------------------------------------
-// LDS per wavefront: `words` uint32 bitmap words covering columns [cmin & ~31, cmax].
+// LDS per wavefront: `words` pairs {bitmap word, number of set bits before it} covering columns
+// [cmin & ~31, cmax].
+//
+// B rows are runs of neighbouring columns, so many lanes of one instruction would OR into the
+// same bitmap word and the LDS would serialise them.  Lanes first combine their bits inside
+// each 16-lane row (an OR-scan over lanes that share the word), and only the last lane of every
+// run issues the LDS atomic.
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                  uint32_t words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform on the scalar unit
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (idx >= nrows) return;
-  uint32_t *bm = reinterpret_cast<uint32_t *>(smem) + (size_t)w * words;
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem) + (size_t)w * words * 2u;
   const uint32_t row = rows[idx];
   const uint32_t base = m.cmin[row] & ~31u;
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
-  for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
+  for (uint32_t i = lane; i < nw; i += 64) reinterpret_cast<uint64_t *>(bm)[i] = 0ull;
   lds_fence();
-  wave_for_each_col(A, B, row, lane, [&](uint32_t col) {
+  wave_row_walk<false>(A, B, row, lane, [&](uint32_t col, double, double) {
     uint32_t c = col - base;
-    atomicOr(&bm[c >> 5], 1u << (c & 31u));
+    atomicOr(&bm[(c >> 5) * 2u], 1u << (c & 31u));
   });
   lds_fence();
-  // enumerate set bits in ascending order -> sorted structural columns
+#if !SG_SYM_ENUM_SEARCH
   uint32_t *out = m.temp_cols + m.t_off[row];
   uint32_t carry = 0;
   for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
     uint32_t wi = r0 + lane;
-    uint32_t bits = wi < nw ? bm[wi] : 0u;
+    uint32_t bits = wi < nw ? bm[wi * 2u] : 0u;
     uint32_t pc = __popc(bits);
     uint32_t incl = group_incl_scan<64>(pc);
     uint32_t pos = carry + incl - pc;
@@ -549,11 +668,36 @@ __global__ void __launch_bounds__(256)
       out[pos++] = cbase + b;
       bits &= bits - 1u;
     }
-    carry += __shfl(incl, 63, 64);
+    carry += group_last<64>(incl);
   }
+  const uint32_t n = carry;
+#else
+  // per-word prefix of the set-bit counts
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t pc = wi < nw ? __popc(bm[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<64>(pc);
+    if (wi < nw) bm[wi * 2u + 1u] = carry + incl - pc;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  // output position p -> word holding the p-th set bit (binary search on the prefixes) -> column
+  const uint32_t n = carry;
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t lo = 0, hi = nw - 1u;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi + 1u) >> 1;
+      if (bm[mid * 2u + 1u] <= p) lo = mid; else hi = mid - 1u;
+    }
+    uint2 e = *reinterpret_cast<const uint2 *>(&bm[lo * 2u]);
+    out[p] = base + (lo << 5) + select_bit(e.x, p - e.y);
+  }
+#endif
   if (lane == 0) {
-    m.nnz[row] = carry;
-    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry);
+    m.nnz[row] = n;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
   }
 }
 
@@ -566,7 +710,8 @@ __global__ void __launch_bounds__(256)
     k_sym_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                uint32_t log2s) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (idx >= nrows) return;
   const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
@@ -578,7 +723,7 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
   lds_fence();
   uint32_t mine = 0;
-  wave_for_each_col(A, B, row, lane, [&](uint32_t c) {
+  wave_row_walk<false>(A, B, row, lane, [&](uint32_t c, double, double) {
     uint32_t h = hash_slot(c, log2s);
     for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
       uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
@@ -606,7 +751,7 @@ __global__ void __launch_bounds__(256)
     uint32_t v = cnt[r0 + lane]; // NB is a multiple of 64
     uint32_t incl = group_incl_scan<64>(v);
     cnt[r0 + lane] = carry + incl - v;
-    carry += __shfl(incl, 63, 64);
+    carry += group_last<64>(incl);
   }
   lds_fence();
   // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
@@ -753,7 +898,9 @@ __global__ void __launch_bounds__(256)
     k_num_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
                  uint32_t words, uint32_t cap, uint32_t gpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lg = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  const uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t gid = threadIdx.x / G;
+  if constexpr (G == 64) gid = __builtin_amdgcn_readfirstlane(gid); // one row per wavefront: scalar row state
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
   if (gid >= gpb || idx >= nrows) return;
   const size_t region = (size_t)words * 8u + (size_t)cap * 8u;
@@ -782,15 +929,19 @@ __global__ void __launch_bounds__(256)
     uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
     uint32_t incl = group_incl_scan<G>(pc);
     if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
-    carry += __shfl(incl, G - 1, G);
+    carry += group_last<G>(incl);
   }
   lds_fence();
-  for_each_product<G>(A, B, row, lg, [&](uint32_t c, double p) {
+  auto acc = [&](uint32_t c, double p) {
     uint32_t cc = c - base;
     uint64_t e = bmp[cc >> 5];
     uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
     if (pos < n) lds_add_f64(&vals[pos], p);
-  });
+  };
+  if constexpr (G == 64)
+    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av) { acc(c, __dmul_rn(av, bv)); });
+  else
+    for_each_product<G>(A, B, row, lg, acc);
   lds_fence();
   uint32_t nz = 0;
   for (uint32_t p = lg; p < n; p += G) {
@@ -811,7 +962,9 @@ __global__ void __launch_bounds__(256)
     k_num_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
                uint32_t log2s, uint32_t gpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lg = threadIdx.x & (G - 1), gid = threadIdx.x / G;
+  const uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t gid = threadIdx.x / G;
+  if constexpr (G == 64) gid = __builtin_amdgcn_readfirstlane(gid);
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
   if (gid >= gpb || idx >= nrows) return;
   const uint32_t S = 1u << log2s, mask = S - 1u;
@@ -836,12 +989,16 @@ __global__ void __launch_bounds__(256)
     if (it < S) pos[h] = (uint16_t)p;
   }
   lds_fence();
-  for_each_product<G>(A, B, row, lg, [&](uint32_t c, double p) {
+  auto acc = [&](uint32_t c, double p) {
     uint32_t h = hash_slot(c, log2s);
     uint32_t it = 0;
     while (keys[h] != c && it < S) { h = (h + 1u) & mask; ++it; }
     if (it < S) lds_add_f64(&vals[pos[h]], p);
-  });
+  };
+  if constexpr (G == 64)
+    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av) { acc(c, __dmul_rn(av, bv)); });
+  else
+    for_each_product<G>(A, B, row, lg, acc);
   lds_fence();
   uint32_t nz = 0;
   for (uint32_t p = lg; p < n; p += G) {
@@ -884,13 +1041,13 @@ __global__ void __launch_bounds__(64)
       uint32_t incl = group_incl_scan<64>(pc);
       if (wi <= w1 && bits)
         __hip_atomic_store(&bmp32[(size_t)wi * 2u + 1u], carry + incl - pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      carry += __shfl(incl, 63, 64);
+      carry += group_last<64>(incl);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    for_each_product<64>(A, B, row, lane, [&](uint32_t c, double p) {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av) {
       unsigned long long e = __hip_atomic_load(&bmp[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (c & 31u)) - 1u));
-      if (pos < n) unsafeAtomicAdd(&o.c_val[off + pos], p);
+      if (pos < n) unsafeAtomicAdd(&o.c_val[off + pos], __dmul_rn(av, bv));
     });
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     uint32_t nz = 0;

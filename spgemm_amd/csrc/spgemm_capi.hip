@@ -674,11 +674,10 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     if (!cnt64) continue;
     uint32_t cnt = (uint32_t)cnt64;
     const uint32_t *rows_bin = perm + boff[key];
-    uint32_t gsel = key & 3;
     if (key < SYM_HASH0) {
       uint32_t tier = key >> 2;
       uint32_t words = (64u << tier) + 2u;
-      size_t region = (size_t)words * 4;
+      size_t region = (size_t)words * 8;
       uint32_t wpb = 4;
       st.rows_window += cnt;
       TRY(prof_begin(ctx, 0, 0, 64, cnt, words, 0, region * wpb, rows_bin));
