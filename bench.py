@@ -165,9 +165,11 @@ def main():
                     help="distributed variant (N > 1): all sections, bitmap-filtered sections, "
                          "or random row/column shuffle + bitmap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true",
+                    help="use the distributed operator even at N = 1 (rehearsal of the N > 1 path)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus == 1 and world == 1:
+    if args.gpus == 1 and world == 1 and not args.dist:
         run_single(args)
     else:
         from spgemm_amd import dist

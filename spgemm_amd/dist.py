@@ -1,0 +1,357 @@
+"""Row-block distributed C = A * B on one node: one process per GPU, torch.distributed for the
+exchange (backend "nccl" = RCCL over xGMI on GPUs; "gloo" on CPU for the plumbing tests).
+
+What is kept from the reference (src/main.cpp:213-217, src/mults/drop_at_once_parallel.cpp):
+  * rank r owns the rows A_shuffle[start_row:end_row] of A, in that order, and produces the same
+    rows of C with local row ids and shuffled-global column ids (column p stands for original
+    column B_shuffle[p]); the inner dimension k is never permuted;
+  * the 512-bit section bitmap of src/bitmap.cpp decides which row sections of B a rank needs
+    (`drop`); without it every section is sent (`baseline`); `shuffle` applies a seeded random
+    row/column permutation first.
+
+What is different, on purpose: B is distributed by ROW SECTIONS (section s = rows
+[s*(n/N), (s+1)*(n/N)), last one to n), not by column blocks.  Rank r initially owns the sections
+[r*N/P, (r+1)*N/P).  One all-to-all moves, to every rank, exactly the sections its bitmap marks;
+the receiver's buffers ARE the col_idx/val arrays of its local B (sections arrive in ascending
+order), so it runs ONE full-width Gustavson multiply instead of P partial ones.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .hostcsr import HostCsr
+
+Partition = Tuple[int, int, int, int]
+
+
+# ---- host-side set-up (integer work, numpy) ---------------------------------------------------------
+
+def section_bounds(n: int, n_sections: int) -> np.ndarray:
+    """Row bounds of the row sections of a matrix with n rows (reference
+    include/matrix_impl.hpp:628-639): all sections have n // N rows, the last one the rest."""
+    sh = n // n_sections
+    if sh == 0:
+        raise ValueError("fewer rows than sections (the reference asserts section_width > 0)")
+    b = np.arange(n_sections + 1, dtype=np.int64) * sh
+    b[-1] = n
+    return b
+
+
+def section_owner_bounds(n_sections: int, world: int) -> np.ndarray:
+    """Rank r owns sections [b[r], b[r+1])."""
+    return (np.arange(world + 1, dtype=np.int64) * n_sections) // world
+
+
+def make_shuffles(n_rows: int, n_cols: int, impl: str, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    from . import capi
+    if impl == "shuffle":
+        return capi.shuffle_random(n_rows, seed).astype(np.int64), capi.shuffle_random(n_cols, seed + 1).astype(np.int64)
+    return np.arange(n_rows, dtype=np.int64), np.arange(n_cols, dtype=np.int64)
+
+
+def select_rows(M: HostCsr, keep: np.ndarray) -> HostCsr:
+    keep = np.asarray(keep, dtype=np.int64)
+    starts = M.row_ptr[keep].astype(np.int64)
+    lens = (M.row_ptr[keep + 1] - M.row_ptr[keep]).astype(np.int64)
+    row_ptr = np.zeros(len(keep) + 1, dtype=np.uint64)
+    row_ptr[1:] = np.cumsum(lens)
+    total = int(lens.sum())
+    if total == 0:
+        return HostCsr(len(keep), M.cols, row_ptr, np.zeros(0, np.uint32), np.zeros(0))
+    idx = np.ones(total, dtype=np.int64)
+    nz = lens > 0
+    s, l = starts[nz], lens[nz]
+    ends = np.cumsum(l)
+    idx[0] = s[0]
+    idx[ends[:-1]] = s[1:] - (s[:-1] + l[:-1] - 1)
+    idx = np.cumsum(idx)
+    return HostCsr(len(keep), M.cols, row_ptr, M.col_idx[idx], M.val[idx])
+
+
+def relabel_cols(M: HostCsr, new_id: np.ndarray) -> HostCsr:
+    """Column c becomes new_id[c]; rows are re-sorted by the new ids."""
+    c = new_id[M.col_idx.astype(np.int64)]
+    order = np.lexsort((c, M.row_ids()))
+    return HostCsr(M.rows, M.cols, M.row_ptr.copy(), c[order].astype(np.uint32), M.val[order])
+
+
+@dataclass
+class RankOperands:
+    A_part: HostCsr       # my rows of A (shuffled order), original column ids (= k)
+    B_block: HostCsr      # my row sections of B, columns relabelled to shuffled-global ids
+    first_row: int        # first global row (k) of B_block
+    n: int                # rows of B / inner dimension
+    n_cols: int           # columns of C
+
+
+def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partitions: Sequence[Partition],
+                        A_shuffle: np.ndarray, B_shuffle: np.ndarray, n_sections: int) -> RankOperands:
+    p = partitions[rank]
+    A_part = select_rows(A, A_shuffle[p[0]:p[1]])
+    sb = section_bounds(B.rows, n_sections)
+    ob = section_owner_bounds(n_sections, world)
+    r0, r1 = int(sb[ob[rank]]), int(sb[ob[rank + 1]])
+    blk = select_rows(B, np.arange(r0, r1, dtype=np.int64))
+    inv = np.empty(B.cols, dtype=np.int64)
+    inv[B_shuffle] = np.arange(B.cols, dtype=np.int64)
+    if not np.array_equal(B_shuffle, np.arange(B.cols)):
+        blk = relabel_cols(blk, inv)
+    return RankOperands(A_part, blk, r0, B.rows, B.cols)
+
+
+# ---- the exchange (torch tensors, any device) -----------------------------------------------------------
+
+class SectionExchange:
+    """All-to-all of B row sections.  Holds this rank's B block as torch tensors and, from the
+    gathered bitmaps and the global per-section entry counts, the split sizes of the collective.
+    `run()` returns (row_ptr int64[n+1], col int32[nnz], val float64[nnz]) of the local B."""
+
+    def __init__(self, ops: RankOperands, n_sections: int, bitmaps: np.ndarray, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n, self.N, self.device = ops.n, n_sections, device
+        self.bitmaps = np.asarray(bitmaps, dtype=bool)            # [world, N]
+        assert self.bitmaps.shape == (self.world, n_sections)
+        self.sb = section_bounds(ops.n, n_sections)
+        self.ob = section_owner_bounds(n_sections, self.world)
+        blk = ops.B_block
+        self.row_len = torch.from_numpy(np.diff(blk.row_ptr.astype(np.int64)).astype(np.int32)).to(device)
+        self.col = torch.from_numpy(blk.col_idx.view(np.int32).copy()).to(device)
+        self.val = torch.from_numpy(blk.val.copy()).to(device)
+        # entries per section, globally: every section is owned by exactly one rank
+        my_lo, my_hi = int(self.ob[self.rank]), int(self.ob[self.rank + 1])
+        rp = blk.row_ptr.astype(np.int64)
+        sec_nnz = np.zeros(n_sections, dtype=np.int64)
+        loc = self.sb[my_lo:my_hi + 1] - ops.first_row
+        sec_nnz[my_lo:my_hi] = rp[loc[1:]] - rp[loc[:-1]]
+        t = torch.from_numpy(sec_nnz).to(device)
+        dist.all_reduce(t, group=group)
+        self.sec_nnz = t.cpu().numpy()
+        self.sec_rows = np.diff(self.sb)
+        self.local_nnz_start = rp[loc[:-1]]                       # start of my sections in my arrays
+        self.local_row_start = loc[:-1]
+        # what I send to each destination: runs of my sections that the destination marks
+        self.send_runs: List[List[Tuple[int, int, int, int]]] = []  # per dest: (row0,row1,nnz0,nnz1)
+        self.send_rows, self.send_nnz = [], []
+        for d in range(self.world):
+            runs, rows, nnz = [], 0, 0
+            s = my_lo
+            while s < my_hi:
+                if not self.bitmaps[d, s]:
+                    s += 1
+                    continue
+                e = s
+                while e + 1 < my_hi and self.bitmaps[d, e + 1]:
+                    e += 1
+                r0, r1 = int(loc[s - my_lo]), int(loc[e - my_lo + 1])
+                z0, z1 = int(rp[r0]), int(rp[r1])
+                runs.append((r0, r1, z0, z1))
+                rows += r1 - r0
+                nnz += z1 - z0
+                s = e + 1
+            self.send_runs.append(runs)
+            self.send_rows.append(rows)
+            self.send_nnz.append(nnz)
+        # what I receive from each source: my marked sections among the source's
+        mine = self.bitmaps[self.rank]
+        self.recv_rows = [int(self.sec_rows[self.ob[s]:self.ob[s + 1]][mine[self.ob[s]:self.ob[s + 1]]].sum())
+                          for s in range(self.world)]
+        self.recv_nnz = [int(self.sec_nnz[self.ob[s]:self.ob[s + 1]][mine[self.ob[s]:self.ob[s + 1]]].sum())
+                         for s in range(self.world)]
+        # rows of the full-height B that are present locally (ascending)
+        present = np.zeros(self.n, dtype=bool)
+        for s in np.flatnonzero(mine):
+            present[self.sb[s]:self.sb[s + 1]] = True
+        self.present_idx = torch.from_numpy(np.flatnonzero(present)).to(device)
+        self.bytes_sent_per_run = sum(4 * r + 12 * z for d, (r, z) in enumerate(zip(self.send_rows, self.send_nnz))
+                                      if d != self.rank)
+
+    def _pack(self, src, runs_key: int):
+        torch = self.torch
+        parts = []
+        for d in range(self.world):
+            for (r0, r1, z0, z1) in self.send_runs[d]:
+                parts.append(src[r0:r1] if runs_key == 0 else src[z0:z1])
+        if not parts:
+            return src[:0]
+        return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+
+    def run(self):
+        torch, dist = self.torch, self.dist
+        send_len = self._pack(self.row_len, 0)
+        send_col = self._pack(self.col, 1)
+        send_val = self._pack(self.val, 1)
+        recv_len = torch.empty(sum(self.recv_rows), dtype=torch.int32, device=self.device)
+        recv_col = torch.empty(sum(self.recv_nnz), dtype=torch.int32, device=self.device)
+        recv_val = torch.empty(sum(self.recv_nnz), dtype=torch.float64, device=self.device)
+        dist.all_to_all_single(recv_len, send_len, self.recv_rows, self.send_rows, group=self.group)
+        dist.all_to_all_single(recv_col, send_col, self.recv_nnz, self.send_nnz, group=self.group)
+        dist.all_to_all_single(recv_val, send_val, self.recv_nnz, self.send_nnz, group=self.group)
+        # full-height row pointer: absent rows are empty
+        full_len = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+        full_len[self.present_idx + 1] = recv_len.to(torch.int64)
+        row_ptr = torch.cumsum(full_len, dim=0)
+        return row_ptr, recv_col, recv_val
+
+
+def gather_bitmaps(my_bits: np.ndarray, device, group=None) -> np.ndarray:
+    """All-gather of the per-rank section bitmaps (reference src/main.cpp:238-240)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(np.asarray(my_bits, dtype=np.uint8)).to(device)
+    out = torch.empty(world * len(my_bits), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().numpy().reshape(world, len(my_bits)).astype(bool)
+
+
+# ---- the distributed operator (GPU) ------------------------------------------------------------------------
+
+class DistSpgemm:
+    """Per-rank operator: mirrors the surface of the reference's mults classes
+    (include/mults.hpp:17-33): construct once, `gemm()` per run (replaces reset() + gemm()),
+    `result()` for the rank's rows of C."""
+
+    def __init__(self, A: HostCsr, B: Optional[HostCsr], impl: str = "drop", n_sections: int = 512, seed: int = 1,
+                 partition: str = "naive", device_index: Optional[int] = None, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        if impl not in ("baseline", "drop", "shuffle"):
+            raise ValueError("impl must be baseline, drop or shuffle")
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.impl, self.N = impl, n_sections
+        B = A if B is None else B
+        if device_index is None:
+            device_index = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.ctx = capi.Context(device_index)
+        # run the kernels on torch's current stream: the exchange's tensors are produced there
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.A_shuffle, self.B_shuffle = make_shuffles(A.rows, B.cols, impl, seed)
+        if partition == "naive":
+            self.partitions = capi.partition_naive(A.rows, B.cols, self.world)
+        else:
+            raise ValueError("only the naive partition is wired into DistSpgemm")
+        self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
+                                       n_sections)
+        ap = self.ops.A_part
+        self.dA = self.ctx.from_host(ap.rows, ap.cols, ap.row_ptr, ap.col_idx, ap.val)
+        if impl == "baseline":
+            bits = np.ones(n_sections, dtype=bool)
+        else:
+            bits = self.ctx.section_bitmap(self.dA, n_sections)   # device-built, reference rule
+        self.bitmap = bits
+        self.bitmaps = gather_bitmaps(bits, self.device, group)
+        self.exchange = SectionExchange(self.ops, n_sections, self.bitmaps, self.device, group)
+        self.C = None
+        self._keep = None
+
+    def gemm(self):
+        """One timed run: exchange of the needed B sections + the local multiply."""
+        if self.C is not None:
+            self.C.free()
+            self.C = None
+        row_ptr, col, val = self.exchange.run()
+        n = self.ops.n
+        dB = self.ctx.wrap_device(n, self.ops.n_cols, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(),
+                                  val.data_ptr(), validate=False, keepalive=(row_ptr, col, val))
+        self.C = self.ctx.multiply(self.dA, dB)
+        self.last_stats = self.ctx.stats()
+        dB.free()
+        return self.C
+
+    def result(self) -> HostCsr:
+        rp, ci, v = self.C.to_host()
+        return HostCsr(self.ops.A_part.rows, self.ops.n_cols, rp, ci, v)
+
+    def close(self):
+        if self.C is not None:
+            self.C.free()
+        self.dA.free()
+        self.ctx.close()
+
+
+def merge_unshuffle(parts: Sequence[HostCsr], partitions: Sequence[Partition], A_shuffle: np.ndarray,
+                    B_shuffle: np.ndarray, n_rows: int, n_cols: int) -> HostCsr:
+    """Merge the per-rank results into the unshuffled C (what the reference's
+    scripts/postprocessing.py:44-79 does with C_<rank>.mtx, A_shuffle, B_shuffle, partitions.csv)."""
+    rs, cs, vs = [], [], []
+    for C, p in zip(parts, partitions):
+        rs.append(A_shuffle[C.row_ids() + p[0]])
+        cs.append(B_shuffle[C.col_idx.astype(np.int64)])
+        vs.append(C.val)
+    return HostCsr.from_coo(n_rows, n_cols, np.concatenate(rs), np.concatenate(cs), np.concatenate(vs)).sorted_rows()
+
+
+# ---- bench entry for N > 1 -----------------------------------------------------------------------------------
+
+def bench_main(args):
+    import torch
+    import torch.distributed as dist
+    import bench as bench_mod
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    A, name = bench_mod.make_workload(args)
+    op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local)
+    for _ in range(args.warmup):
+        op.gemm()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op.gemm()
+    op.ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    st = op.last_stats
+    t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.exchange.bytes_sent_per_run,
+                         st["bytes_algorithmic"]], dtype=torch.float64, device="cuda")
+    dist.all_reduce(sums)
+    drop = torch.tensor([1.0 - float(np.mean(op.bitmap))], dtype=torch.float64, device="cuda")
+    dist.all_reduce(drop)
+    mult_ms = torch.tensor([st["ms_total"]], dtype=torch.float64, device="cuda")
+    dist.all_reduce(mult_ms, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ms_per_step = float(t.item()) * 1e3 / args.steps
+        nprod, nnz_c, nnz_a, nnz_b_local, sent, b_alg = (float(x) for x in sums.tolist())
+        out = {
+            "metric": "SpGEMM GFLOP/s (useful flops, 2*nprod/t) C=A*A fp64",
+            "value": 2.0 * nprod / (ms_per_step * 1e-3) / 1e9, "unit": "GFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if args.workload != "mtx" else "file",
+            "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": int(nprod), "nnz_c": int(nnz_c),
+                       "impl": args.impl, "n_sections": 512,
+                       "parallelism": f"{world} GPUs, A by row blocks, B row sections by all-to-all (RCCL)"},
+            "exchange": {"bytes_sent_all_ranks_per_step": int(sent), "b_entries_resident_all_ranks": int(nnz_b_local),
+                         "mean_section_drop_fraction": float(drop.item()) / world},
+            "whole_multiply": {"algorithmic_bytes_all_ranks": int(b_alg),
+                               "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9,
+                               "frac_of_hbm_peak_all_gpus": b_alg / (ms_per_step * 1e-3) / 1e9 / (8000.0 * world),
+                               "slowest_rank_multiply_ms": float(mult_ms.item())},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    op.close()
+    dist.destroy_process_group()
