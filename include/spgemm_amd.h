@@ -81,6 +81,7 @@ int spgemm_device_count(int *count);
  *      object (include/mults.hpp:17-33) ----------------------------------------------------- */
 int spgemm_create(int device, spgemm_ctx **ctx);
 int spgemm_destroy(spgemm_ctx *ctx);
+int spgemm_ctx_device(const spgemm_ctx *ctx, int *device);
 /* Run on a caller-owned hipStream_t (e.g. the framework's current stream). NULL restores the
  * context's own stream. */
 int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
@@ -196,6 +197,15 @@ int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sectio
 int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
                             const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
                             uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out);
+
+/* ---- raw device buffers for the exchange: what the reference keeps in std::vector<std::byte>
+ *      receive buffers (src/mults/drop_parallel.cpp:65-68) lives in HBM here.  copy moves bytes
+ *      between two contexts' devices (peer-to-peer over xGMI when they differ; the analogue of
+ *      communication::send / recv, src/communication.cpp:11-22) and is ordered after the work
+ *      already queued on the source context and before later work of the destination context. */
+int spgemm_buffer_alloc(spgemm_ctx *ctx, size_t bytes, void **d_ptr);
+int spgemm_buffer_free(spgemm_ctx *ctx, void *d_ptr);
+int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, const void *d_src, size_t bytes);
 
 #ifdef __cplusplus
 }

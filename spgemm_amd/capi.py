@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SPGEMM_AMD_LIB") or os.path.join(_HERE, "libspgemm_am
 # every symbol include/spgemm_amd.h declares
 EXPORTED_SYMBOLS = [
     "spgemm_version", "spgemm_last_error", "spgemm_device_count",
-    "spgemm_create", "spgemm_destroy", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option",
+    "spgemm_create", "spgemm_destroy", "spgemm_ctx_device", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option",
     "spgemm_mat_from_host", "spgemm_mat_wrap_device", "spgemm_mat_info", "spgemm_mat_device_ptrs",
     "spgemm_mat_to_host", "spgemm_mat_free",
     "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
     "spgemm_shuffle_random", "spgemm_mat_select",
     "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr",
+    "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy",
 ]
 
 
@@ -91,6 +92,7 @@ def load() -> ctypes.CDLL:
         "spgemm_device_count": (i32, [ctypes.POINTER(i32)]),
         "spgemm_create": (i32, [i32, pp]),
         "spgemm_destroy": (i32, [vp]),
+        "spgemm_ctx_device": (i32, [vp, ctypes.POINTER(i32)]),
         "spgemm_set_stream": (i32, [vp, vp]),
         "spgemm_synchronize": (i32, [vp]),
         "spgemm_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
@@ -115,6 +117,9 @@ def load() -> ctypes.CDLL:
         "spgemm_pack_sections": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, vp, ctypes.POINTER(u64),
                                        ctypes.POINTER(u64)]),
         "spgemm_assemble_row_ptr": (i32, [vp, u64, u32, vp, vp, u64, vp, ctypes.POINTER(u64)]),
+        "spgemm_buffer_alloc": (i32, [vp, ctypes.c_size_t, pp]),
+        "spgemm_buffer_free": (i32, [vp, vp]),
+        "spgemm_buffer_copy": (i32, [vp, vp, vp, vp, ctypes.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

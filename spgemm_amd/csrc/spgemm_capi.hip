@@ -83,6 +83,7 @@ struct spgemm_ctx {
   void *h_pinned = nullptr; // small host staging buffer
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
+  std::vector<Block> buffers; // live blocks handed out by spgemm_buffer_alloc
   size_t pool_bytes = 0;
   spgemm_stats stats;
   // per-launch profile (option "profile_launches")
@@ -334,6 +335,7 @@ extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
+  for (auto &b : ctx->buffers) (void)hipFree(b.p);
   if (ctx->arena.p) (void)hipFree(ctx->arena.p);
   if (ctx->temp_cols.p) (void)hipFree(ctx->temp_cols.p);
   if (ctx->gscratch.p) (void)hipFree(ctx->gscratch.p);
@@ -344,6 +346,12 @@ extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   for (auto &ev : ctx->prof_events) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_ctx_device(const spgemm_ctx *ctx, int *device) {
+  if (!ctx || !device) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *device = ctx->device;
   return SPGEMM_OK;
 }
 
@@ -1277,5 +1285,45 @@ extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *nnz_out = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
   }
+  return SPGEMM_OK;
+}
+
+// ---- raw device buffers -------------------------------------------------------------------------------------
+extern "C" int spgemm_buffer_alloc(spgemm_ctx *ctx, size_t bytes, void **d_ptr) {
+  if (!ctx || !d_ptr) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  void *p = nullptr;
+  size_t got = 0;
+  TRY(pool_alloc(ctx, bytes, &p, &got));
+  // remember the block size on the host side so that free can return it to the pool
+  ctx->buffers.push_back({p, got});
+  *d_ptr = p;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_buffer_free(spgemm_ctx *ctx, void *d_ptr) {
+  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
+  if (!d_ptr) return SPGEMM_OK;
+  for (size_t i = 0; i < ctx->buffers.size(); ++i)
+    if (ctx->buffers[i].p == d_ptr) {
+      (void)hipSetDevice(ctx->device);
+      (void)hipStreamSynchronize(ctx->stream);
+      pool_release(ctx, d_ptr, ctx->buffers[i].bytes);
+      ctx->buffers.erase(ctx->buffers.begin() + i);
+      return SPGEMM_OK;
+    }
+  return fail(SPGEMM_ERR_INVALID, "pointer was not allocated by spgemm_buffer_alloc on this context");
+}
+
+extern "C" int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, const void *d_src, size_t bytes) {
+  if (!dst_ctx || !src_ctx || (bytes && (!d_dst || !d_src))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (!bytes) return SPGEMM_OK;
+  HIP_TRY(hipSetDevice(src_ctx->device));
+  HIP_TRY(hipStreamSynchronize(src_ctx->stream));
+  HIP_TRY(hipSetDevice(dst_ctx->device));
+  if (dst_ctx->device == src_ctx->device)
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream));
+  else
+    HIP_TRY(hipMemcpyPeerAsync(d_dst, dst_ctx->device, d_src, src_ctx->device, bytes, dst_ctx->stream));
   return SPGEMM_OK;
 }

@@ -1,0 +1,82 @@
+// Partitions and shuffles of the host driver (interface of the reference's include/partition.hpp
+// and include/parts.hpp; the integer work is done by the C ABI).
+#pragma once
+
+#include "../../include/spgemm_amd.h"
+#include "matrix.hpp"
+
+#include <fstream>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace partition {
+
+using Partition = spgemm_partition; // {start_row, end_row, start_col, end_col}, reference include/partition.hpp:10-15
+typedef std::vector<Partition> Partitions;
+typedef std::vector<midx_t> Shuffle;
+
+// Random permutation (reference src/partition.cpp:15-37), seeded so that runs can be repeated.
+inline Shuffle shuffle(size_t size, uint64_t seed) {
+  Shuffle s(size);
+  if (spgemm_shuffle_random((uint32_t)size, seed, s.data()) != SPGEMM_OK) throw std::runtime_error(spgemm_last_error());
+  return s;
+}
+
+inline Shuffle identity(size_t size) {
+  Shuffle s(size);
+  std::iota(s.begin(), s.end(), 0u);
+  return s;
+}
+
+// reference src/partition.cpp:204-217
+inline void save_partitions(const Partitions &p, const std::string &file) {
+  std::ofstream csv(file);
+  if (csv.fail()) throw std::runtime_error("cannot write " + file);
+  csv << "rank,start_row,end_row,start_col,end_col" << std::endl;
+  for (size_t i = 0; i < p.size(); ++i)
+    csv << i << "," << p[i].start_row << "," << p[i].end_row << "," << p[i].start_col << "," << p[i].end_col << std::endl;
+}
+
+// one integer per line (reference src/partition.cpp:219-252)
+inline void save_shuffle(const Shuffle &s, const std::string &file) {
+  std::ofstream out(file);
+  if (out.fail()) throw std::runtime_error("cannot write " + file);
+  for (auto i : s) out << i << "\n";
+}
+
+inline bool load_shuffle(const std::string &file, Shuffle &s) {
+  std::ifstream in(file);
+  if (!in.is_open()) return false;
+  size_t idx = 0;
+  unsigned long long v;
+  while (in >> v) {
+    if (idx >= s.size()) return false;
+    s[idx++] = (midx_t)v;
+  }
+  return idx == s.size();
+}
+
+} // namespace partition
+
+namespace parts {
+namespace baseline {
+
+// Equal rows and columns, remainder spread over the first parts (reference src/parts/baseline.cpp:10-42).
+inline partition::Partitions partition(const matrix::Fields &f, int n_parts) {
+  partition::Partitions p(n_parts);
+  if (spgemm_partition_naive(f.height, f.width, n_parts, p.data()) != SPGEMM_OK) throw std::runtime_error(spgemm_last_error());
+  return p;
+}
+
+// Rows cut where the running weight exceeds total / n_parts (reference src/parts/baseline.cpp:44-86
+// weighs rows by nnz of C_sparsity; any weight works, the driver passes per-row product counts).
+inline partition::Partitions balanced_partition(const std::vector<uint64_t> &row_weight, midx_t width, int n_parts) {
+  partition::Partitions p(n_parts);
+  if (spgemm_partition_balanced(row_weight.data(), (uint32_t)row_weight.size(), width, n_parts, p.data()) != SPGEMM_OK)
+    throw std::runtime_error(spgemm_last_error());
+  return p;
+}
+
+} // namespace baseline
+} // namespace parts
