@@ -126,7 +126,8 @@ def run_single(args):
         achieved = b / (dom["ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": f"k_num_{dom['path']}<{dom['lanes']}>", "kernel_ms": dom["ms"],
+                    "kernel": "k_num_window_grp" if dom["path"] == "window_groups" else f"k_num_{dom['path']}<{dom['lanes']}>",
+                    "kernel_ms": dom["ms"],
                     "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b}
     b_all = st["bytes_algorithmic"]
     gflops = 2.0 * st["nprod"] / (ms_per_step * 1e-3) / 1e9

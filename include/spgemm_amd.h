@@ -60,10 +60,10 @@ typedef struct spgemm_stats {
   uint64_t nnz_c;          /* after dropping exact zeros */
   uint64_t bytes_algorithmic; /* 12*(nnzA+nprod+nnzC) + 4*(rowsA+1) + 8*(rowsC+1) */
   uint64_t temp_bytes;     /* scratch held by the context after this multiply */
-  uint32_t rows_window;    /* rows accumulated through an LDS bitmap window */
+  uint32_t rows_window;    /* symbolic passes through an LDS bitmap window (one per row or row group) */
   uint32_t rows_hash;      /* rows accumulated through an LDS hash table */
   uint32_t rows_global;    /* rows accumulated in global-memory scratch */
-  uint32_t rows_empty;
+  uint32_t rows_empty;     /* rows without a symbolic pass: no products, or follower of a row group */
   float ms_analyze;        /* B row info + A row analysis + binning */
   float ms_symbolic;
   float ms_scan;
@@ -130,7 +130,7 @@ int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out);
  * measure points are per phase (include/measure.hpp:16-30). */
 typedef struct spgemm_launch_info {
   uint32_t phase;  /* 0 symbolic, 1 numeric */
-  uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch */
+  uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch, 3 window for row groups */
   uint32_t lanes;  /* lanes per A entry (symbolic) or per row (numeric) */
   uint32_t rows;   /* rows handled by the launch */
   uint32_t param0; /* window: bitmap words; hash: log2 of the table size */

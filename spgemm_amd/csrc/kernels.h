@@ -28,9 +28,13 @@ constexpr uint32_t KEY_NONE = 255u; // row needs no kernel (no products)
 // numeric:   [0,96)   window, key = (span_tier*4 + cap_tier)*4 + gsel, nnz <= 128 << (2*cap_tier)
 //            [96,112) hash,   key = 96 + cap_tier*4 + gsel,             nnz <= 64 << (2*cap_tier)
 //            112      global
+//            [113,137) window, row groups: key = 113 + span_tier*4 + cap_tier (one wavefront per group
+//                      of up to GRP_MAX consecutive rows of A with identical column lists)
 constexpr int SYM_WIN0 = 0, SYM_HASH0 = 24, SYM_GLOBAL0 = 40, SYM_NBINS = 44;
-constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = 112, NUM_NBINS = 113;
-constexpr int MAX_BINS = 128;
+constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = 112, NUM_GRP0 = 113, NUM_NBINS = 137;
+constexpr int MAX_BINS = 192;
+constexpr uint32_t GRP_MAX = 8;   // rows per group
+constexpr uint32_t GRP_ALEN = 64; // longest A row that is grouped (its values are staged in LDS)
 
 struct ClassParams {
   uint32_t win_max_span;   // window path allowed up to this column span (<= 65536)
@@ -65,13 +69,14 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
   return SYM_GLOBAL0 + g;
 }
 
-__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz) {
+__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t group_rows = 1) {
   if (nnz == 0) return KEY_NONE;
   uint32_t g = sym_key & 3u;
   if (sym_key < (uint32_t)SYM_HASH0) {
     uint32_t st = sym_key >> 2;
     if (nnz <= 8192u) {
       uint32_t ct = nnz <= 128 ? 0u : nnz <= 512 ? 1u : nnz <= 2048 ? 2u : 3u;
+      if (group_rows > 1 && ct <= 1) return NUM_GRP0 + st * 4 + ct;
       return NUM_WIN0 + (st * 4 + ct) * 4 + g;
     }
     return NUM_GLOBAL;
@@ -198,6 +203,7 @@ struct AnalyzeOut {
   uint64_t *total_nprod;   // NPROD_SLOTS partial counters, summed by the host
   uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
   uint32_t *long_count;
+  uint8_t *r_same;         // 1 when the row's column list equals the previous row's (same order)
 };
 
 __device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32_t mn, uint32_t mx,
@@ -230,9 +236,20 @@ __global__ void __launch_bounds__(256)
     a1 = a_ptr[row + 1];
     is_long = (a1 - a0) > long_len;
   }
+  uint32_t differs = 1;
   if (!is_long) {
+    // does the row repeat the previous row's column list?
+    uint64_t p0 = 0;
+    bool cmp = false;
+    if (row > 0 && row < rows_a) {
+      p0 = a_ptr[row - 1];
+      cmp = (a0 - p0) == (a1 - a0) && a1 > a0;
+    }
+    differs = cmp ? 0u : 1u;
     for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
-      uint4 bi = b_info[a_col[ka]];
+      uint32_t kcol = a_col[ka];
+      if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
+      uint4 bi = b_info[kcol];
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);
@@ -240,11 +257,13 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
+  differs = group_max<G>(differs);
   np = group_sum64<G>(np);
   mn = group_min<G>(mn);
   mx = group_max<G>(mx);
   uint64_t contrib = 0;
   if (row < rows_a && lg == 0) {
+    o.r_same[row] = differs ? 0 : 1;
     if (is_long) {
       uint32_t p = atomicAdd(o.long_count, 1u);
       o.long_rows[p] = row;
@@ -304,6 +323,47 @@ __global__ void __launch_bounds__(256)
     }
     __syncthreads();
   }
+}
+
+// ---- row groups ----------------------------------------------------------------------------------
+// Consecutive rows of A with identical column lists (the unknowns of one mesh node, for example)
+// produce identical patterns in C and walk the same B rows.  Such runs are cut into groups of
+// up to GRP_MAX rows; the first row of a group is its leader.  The symbolic pass runs once per
+// group, and the numeric pass loads every B entry and finds its output position once per group,
+// then adds into one accumulator per row.  Only window-path rows with at most GRP_ALEN A
+// entries are grouped.  gcnt: rows in the group for a leader (>= 1), 0 for a follower.
+// Every row decides for itself from the `same` flags around it; the rule (position inside the
+// run modulo GRP_MAX, runs longer than 56 rows stop grouping) gives the same answer from the
+// leader's and from the follower's point of view.
+__global__ void __launch_bounds__(256)
+    k_group(uint32_t rows, const uint64_t *__restrict__ a_ptr, const uint8_t *__restrict__ same,
+            uint8_t *__restrict__ key, uint32_t *__restrict__ ub, uint8_t *__restrict__ gcnt,
+            uint32_t *__restrict__ lead, uint32_t enable) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  lead[i] = i;
+  const uint32_t k = key[i];
+  const uint64_t len = a_ptr[i + 1] - a_ptr[i];
+  if (!enable || k >= (uint32_t)SYM_HASH0 || len > GRP_ALEN) { // not a window row (or no products)
+    gcnt[i] = 1;
+    return;
+  }
+  uint32_t pos = 0; // rows before i that belong to the same run
+  while (pos < 56u && pos < i && same[i - pos]) ++pos;
+  if (pos >= 56u) {
+    gcnt[i] = 1;
+    return;
+  }
+  if (pos % GRP_MAX != 0) { // follower: handled by its leader
+    gcnt[i] = 0;
+    key[i] = (uint8_t)KEY_NONE;
+    ub[i] = 0;
+    lead[i] = i - pos % GRP_MAX;
+    return;
+  }
+  uint32_t c = 1;
+  while (c < GRP_MAX && i + c < rows && same[i + c]) ++c;
+  gcnt[i] = (uint8_t)c;
 }
 
 // ---- exclusive scan (uint32 in, uint64 out), three launches ----------------------------------
@@ -484,6 +544,8 @@ struct RowMeta {
   uint32_t *__restrict__ temp_cols;   // sorted structural columns per row (written by symbolic)
   uint32_t *__restrict__ nnz;         // structural nnz per row
   uint8_t *__restrict__ num_key;      // numeric bin key per row
+  const uint8_t *__restrict__ gcnt;   // rows in the group led by this row (0: follower)
+  const uint32_t *__restrict__ lead;  // leader of the row's group (the row itself when ungrouped)
 };
 
 // ---- walking the products of one row ----------------------------------------------------------
@@ -522,7 +584,8 @@ template <class T> __device__ __forceinline__ const_as_ptr<T> scalar_view(const 
   return (const_as_ptr<T>)(uintptr_t)p;
 }
 
-template <bool WITH_VAL, class F>
+// f(col, bval, aval, apos): apos = position of the A entry inside its row (wave-uniform).
+template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, class F>
 __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
   const auto a_ptr = scalar_view(A.ptr);
   const auto a_col = scalar_view(A.col);
@@ -540,14 +603,14 @@ __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         k[u] = a_col[ka + u];
-        if constexpr (WITH_VAL) av[u] = a_val[ka + u];
+        if constexpr (WITH_AVAL) av[u] = a_val[ka + u];
       }
     } else {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const uint64_t kk = min(ka + u, a1 - 1);
         k[u] = a_col[kk];
-        if constexpr (WITH_VAL) av[u] = a_val[kk];
+        if constexpr (WITH_AVAL) av[u] = a_val[kk];
       }
     }
     // stage 2: bounds of the PF B rows
@@ -572,9 +635,11 @@ __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      if (c[u] != EMPTY_KEY) f(c[u], WITH_VAL ? v[u] : 0.0, WITH_VAL ? av[u] : 0.0);
+      const uint32_t apos = (uint32_t)(ka - a0) + u;
+      if (c[u] != EMPTY_KEY) f(c[u], WITH_VAL ? v[u] : 0.0, WITH_AVAL ? av[u] : 0.0, apos);
       if (len[u] > 64) // wave-uniform
-        for (uint32_t j = 64 + lane; j < len[u]; j += 64) f(pc[u][j], WITH_VAL ? pv[u][j] : 0.0, WITH_VAL ? av[u] : 0.0);
+        for (uint32_t j = 64 + lane; j < len[u]; j += 64)
+          f(pc[u][j], WITH_VAL ? pv[u][j] : 0.0, WITH_AVAL ? av[u] : 0.0, apos);
     }
   }
 }
@@ -648,7 +713,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
   for (uint32_t i = lane; i < nw; i += 64) reinterpret_cast<uint64_t *>(bm)[i] = 0ull;
   lds_fence();
-  wave_row_walk<false>(A, B, row, lane, [&](uint32_t col, double, double) {
+  wave_row_walk<false>(A, B, row, lane, [&](uint32_t col, double, double, uint32_t) {
     uint32_t c = col - base;
     atomicOr(&bm[(c >> 5) * 2u], 1u << (c & 31u));
   });
@@ -695,9 +760,14 @@ __global__ void __launch_bounds__(256)
     out[p] = base + (lo << 5) + select_bit(e.x, p - e.y);
   }
 #endif
-  if (lane == 0) {
-    m.nnz[row] = n;
-    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
+  // the group's rows share the pattern: same nnz; they are accumulated together when the group
+  // kernel has a tier for them, else one by one (each reading the leader's column list)
+  const uint32_t cnt = m.gcnt[row];
+  if (lane < cnt) {
+    m.nnz[row + lane] = n;
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, cnt);
+    const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
+    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n));
   }
 }
 
@@ -723,7 +793,7 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
   lds_fence();
   uint32_t mine = 0;
-  wave_row_walk<false>(A, B, row, lane, [&](uint32_t c, double, double) {
+  wave_row_walk<false>(A, B, row, lane, [&](uint32_t c, double, double, uint32_t) {
     uint32_t h = hash_slot(c, log2s);
     for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
       uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
@@ -912,7 +982,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
   const uint32_t n = m.nnz[row];
   const uint64_t off = o.c_ptr[row];
-  const uint32_t *tin = m.temp_cols + m.t_off[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
   for (uint32_t i = lg; i < nw; i += G) bmp[i] = 0ull;
   for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
   lds_fence();
@@ -939,7 +1009,7 @@ __global__ void __launch_bounds__(256)
     if (pos < n) lds_add_f64(&vals[pos], p);
   };
   if constexpr (G == 64)
-    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av) { acc(c, __dmul_rn(av, bv)); });
+    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av, uint32_t) { acc(c, __dmul_rn(av, bv)); });
   else
     for_each_product<G>(A, B, row, lg, acc);
   lds_fence();
@@ -951,6 +1021,74 @@ __global__ void __launch_bounds__(256)
   }
   nz = group_sum<G>(nz);
   if (lg == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, window path, row groups: one wavefront per group of up to GRP_MAX consecutive rows of
+// A that share their column list.  Every B entry is loaded once and its output position is found
+// once; it is then multiplied by each row's own A value (staged in LDS) and added to that row's
+// accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
+// LDS per wavefront: bmp[words] {bits, prefix} | vals[GRP_MAX][cap] | avals[GRP_MAX][GRP_ALEN].
+__global__ void __launch_bounds__(256)
+    k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                     uint32_t words, uint32_t cap, uint32_t wpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (size_t)GRP_MAX * cap * 8u + (size_t)GRP_MAX * GRP_ALEN * 8u;
+  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  double *vals = reinterpret_cast<double *>(bmp + words);
+  double *avals = vals + (size_t)GRP_MAX * cap;
+  const uint32_t row = rows[idx];
+  const uint32_t cnt = min((uint32_t)m.gcnt[row], GRP_MAX);
+  const uint32_t base = m.cmin[row] & ~31u;
+  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
+  const uint32_t n = m.nnz[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[row];
+  const uint32_t len_a = (uint32_t)(A.ptr[row + 1] - A.ptr[row]);
+  for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
+    const double *av = A.val + A.ptr[row + j];
+    for (uint32_t t = lane; t < len_a && t < GRP_ALEN; t += 64) avals[j * GRP_ALEN + t] = av[t];
+  }
+  lds_fence();
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t c = tin[p];
+    for (uint32_t j = 0; j < cnt; ++j) o.c_col[o.c_ptr[row + j] + p] = c;
+    uint32_t cc = c - base;
+    atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<64>(pc);
+    if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  wave_row_walk<true, false>(A, B, row, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
+    uint32_t cc = c - base;
+    uint64_t e = bmp[cc >> 5];
+    uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+    for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * GRP_ALEN + apos], bv));
+  });
+  lds_fence();
+  uint32_t nz = 0;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const uint64_t off = o.c_ptr[row + j];
+    for (uint32_t p = lane; p < n; p += 64) {
+      double v = vals[j * cap + p];
+      o.c_val[off + p] = v;
+      nz += (v == 0.0) ? 1u : 0u;
+    }
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
 
 // numeric, hash path: G lanes per row.
@@ -976,7 +1114,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t row = rows[idx];
   const uint32_t n = m.nnz[row];
   const uint64_t off = o.c_ptr[row];
-  const uint32_t *tin = m.temp_cols + m.t_off[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
   for (uint32_t i = lg; i < S; i += G) keys[i] = EMPTY_KEY;
   for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
   lds_fence();
@@ -996,7 +1134,7 @@ __global__ void __launch_bounds__(256)
     if (it < S) lds_add_f64(&vals[pos[h]], p);
   };
   if constexpr (G == 64)
-    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av) { acc(c, __dmul_rn(av, bv)); });
+    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av, uint32_t) { acc(c, __dmul_rn(av, bv)); });
   else
     for_each_product<G>(A, B, row, lg, acc);
   lds_fence();
@@ -1023,7 +1161,7 @@ __global__ void __launch_bounds__(64)
     const uint32_t row = rows[idx];
     const uint32_t n = m.nnz[row];
     const uint64_t off = o.c_ptr[row];
-    const uint32_t *tin = m.temp_cols + m.t_off[row];
+    const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
     const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
     for (uint32_t p = lane; p < n; p += 64) {
       uint32_t c = tin[p];
@@ -1044,7 +1182,7 @@ __global__ void __launch_bounds__(64)
       carry += group_last<64>(incl);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av) {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
       unsigned long long e = __hip_atomic_load(&bmp[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (c & 31u)) - 1u));
       if (pos < n) unsafeAtomicAdd(&o.c_val[off + pos], __dmul_rn(av, bv));
@@ -1124,13 +1262,15 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_bin_sums(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
                const uint64_t *__restrict__ r_nprod, const uint32_t *__restrict__ r_nnz,
+               const uint8_t *__restrict__ gcnt, uint32_t whole_groups,
                unsigned long long *__restrict__ out /* nnz_a, nprod, nnz_c */) {
   uint64_t sa = 0, sp = 0, sc = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
     uint32_t r = rows[i];
-    sa += a_ptr[r + 1] - a_ptr[r];
-    sp += r_nprod[r];
-    sc += r_nnz[r];
+    uint64_t mult = whole_groups ? max((uint32_t)gcnt[r], 1u) : 1u; // the launch handled the whole group
+    sa += mult * (a_ptr[r + 1] - a_ptr[r]);
+    sp += mult * r_nprod[r];
+    sc += mult * r_nnz[r];
   }
   sa = group_sum64<64>(sa);
   sp = group_sum64<64>(sp);

@@ -74,6 +74,7 @@ struct spgemm_ctx {
   ClassParams cp;
   size_t lds_budget = 64 * 1024; // LDS bytes per workgroup aimed for (>= 2 workgroups per CU)
   uint32_t long_len = 2048;      // A rows longer than this are analysed by a whole workgroup
+  uint32_t row_groups = 1;       // accumulate runs of identical A rows together
   uint32_t global_blocks_sym = 512;
   uint32_t global_blocks_num = 2048;
   Growable arena;     // per-multiply row arrays
@@ -96,12 +97,14 @@ struct spgemm_ctx {
   };
   std::vector<LaunchRec> launches;
   uint64_t *r_nprod_prof = nullptr;
+  const uint8_t *plan_gcnt = nullptr;
   // state carried from spgemm_symbolic to spgemm_numeric
   struct Plan {
     bool valid = false;
     const spgemm_mat *A = nullptr, *B = nullptr;
     uint32_t *r_cmin = nullptr, *r_cmax = nullptr, *r_nnz = nullptr;
-    uint8_t *r_key = nullptr, *r_numkey = nullptr;
+    uint8_t *r_key = nullptr, *r_numkey = nullptr, *r_gcnt = nullptr;
+    uint32_t *r_lead = nullptr;
     uint64_t *t_off = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *blk_hist = nullptr;
@@ -260,6 +263,7 @@ template <class K> static void raise_lds_limit(K kernel) {
 static void raise_all_lds_limits() {
   if (g_attr_set) return;
   raise_lds_limit(k_sym_window);
+  raise_lds_limit(k_num_window_grp);
   raise_lds_limit(k_sym_hash);
   raise_lds_limit(k_num_window<8>); raise_lds_limit(k_num_window<16>);
   raise_lds_limit(k_num_window<32>); raise_lds_limit(k_num_window<64>);
@@ -392,6 +396,8 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "lds_budget") {
     if (value < 8192 || value > 160 * 1024) return fail(SPGEMM_ERR_INVALID, "lds_budget must be 8192..163840");
     ctx->lds_budget = (size_t)value;
+  } else if (n == "row_groups") {
+    ctx->row_groups = value != 0;
   } else if (n == "profile_launches") {
     if (value > 2) return fail(SPGEMM_ERR_INVALID, "profile_launches is 0, 1 or 2");
     ctx->profile = (int)value;
@@ -565,7 +571,8 @@ static int prof_collect(spgemm_ctx *ctx, const spgemm_mat *A, const uint32_t *r_
     unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_small) + 8;
     HIP_TRY(hipMemsetAsync(d, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_bin_sums, dim3(std::min<uint32_t>(div_up_u64(r.info.rows, 256), 1024)), dim3(256), 0,
-                       ctx->stream, r.rows_bin, r.info.rows, A->d_ptr, ctx->r_nprod_prof, r_nnz, d);
+                       ctx->stream, r.rows_bin, r.info.rows, A->d_ptr, ctx->r_nprod_prof, r_nnz, ctx->plan_gcnt,
+                       (uint32_t)((r.info.phase == 0 && r.info.path == 0) || r.info.path == 3), d);
     HIP_TRY(hipGetLastError());
     unsigned long long h[3];
     HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -617,7 +624,8 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   size_t need = 0;
   need += 4 * align_up((size_t)rows * 4, 256);            // cmin, cmax, ub, nnz
   if (ctx->profile >= 2) need += align_up((size_t)rows * 8, 256) + 256 * 64; // per-row products, per-launch sums
-  need += 2 * align_up((size_t)rows, 256);                // key, numkey
+  need += 4 * align_up((size_t)rows, 256);                // key, numkey, same, gcnt
+  need += align_up((size_t)rows * 4, 256);                // lead
   need += align_up((size_t)rows * 4, 256);                // perm
   need += align_up(((size_t)rows + 1) * 8, 256);          // t_off
   need += align_up((size_t)max_long * 4, 256) + 256;      // long rows + counter
@@ -629,6 +637,8 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint32_t *r_cmin = ar.take<uint32_t>(rows), *r_cmax = ar.take<uint32_t>(rows);
   uint32_t *r_ub = ar.take<uint32_t>(rows), *r_nnz = ar.take<uint32_t>(rows);
   uint8_t *r_key = ar.take<uint8_t>(rows), *r_numkey = ar.take<uint8_t>(rows);
+  uint8_t *r_same = ar.take<uint8_t>(rows), *r_gcnt = ar.take<uint8_t>(rows);
+  uint32_t *r_lead = ar.take<uint32_t>(rows);
   uint32_t *perm = ar.take<uint32_t>(rows);
   uint64_t *t_off = ar.take<uint64_t>((size_t)rows + 1);
   uint32_t *long_rows = ar.take<uint32_t>(max_long);
@@ -641,6 +651,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32));
   uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
   ctx->r_nprod_prof = r_nprod;
+  ctx->plan_gcnt = r_gcnt;
   ctx->launches.clear();
   ctx->arena_used = ar.used;
   if (ar.used > ar.cap) return fail(SPGEMM_ERR_STATE, "internal: arena layout exceeds its size");
@@ -650,12 +661,14 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
   HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
 
-  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count};
+  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   if (max_long > 1 || A->nnz > ctx->long_len)
     hipLaunchKernelGGL(k_analyze_long, dim3(std::min<uint32_t>(max_long, 1024)), dim3(256), 0, ctx->stream, A->d_ptr,
                        A->d_col, B->d_rowinfo, ao, ctx->cp);
+  hipLaunchKernelGGL(k_group, dim3(div_up_u64(rows, 256)), dim3(256), 0, ctx->stream, rows, A->d_ptr, r_same, r_key, r_ub,
+                     r_gcnt, r_lead, ctx->row_groups);
   HIP_TRY(hipGetLastError());
   TRY(launch_scan(ctx, r_ub, rows, t_off, partial));
   PartScratch ps{pblocks, blk_hist, blk_off, partial};
@@ -675,7 +688,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
-  RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey};
+  RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey, r_gcnt, r_lead};
 
   for (int key = 0; key < SYM_NBINS; ++key) {
     uint64_t cnt64 = boff[key + 1] - boff[key];
@@ -725,6 +738,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.A = A; pl.B = B;
   pl.r_cmin = r_cmin; pl.r_cmax = r_cmax; pl.r_nnz = r_nnz;
   pl.r_key = r_key; pl.r_numkey = r_numkey; pl.t_off = t_off; pl.perm = perm;
+  pl.r_gcnt = r_gcnt; pl.r_lead = r_lead;
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
   pl.valid = true;
@@ -759,7 +773,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
   RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
-             pl.r_numkey};
+             pl.r_numkey, pl.r_gcnt, pl.r_lead};
   NumOut no{d_row_ptr, d_col, d_val, zero_count};
   const size_t lds_max = 160 * 1024;
 
@@ -768,7 +782,16 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
     if (!cnt64) continue;
     uint32_t cnt = (uint32_t)cnt64;
     const uint32_t *rows_bin = perm + boff[key];
-    if (key < NUM_GLOBAL) {
+    if (key >= NUM_GRP0) {
+      uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, ct = (uint32_t)(key - NUM_GRP0) & 3;
+      uint32_t words = (64u << st_) + 2u, cap = 128u << (2 * ct);
+      size_t region = (size_t)words * 8 + (size_t)GRP_MAX * cap * 8 + (size_t)GRP_MAX * GRP_ALEN * 8;
+      if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
+      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
+      hipLaunchKernelGGL(k_num_window_grp, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
+                         cnt, cA, cB, rm, no, words, cap, wpb);
+    } else if (key < NUM_GLOBAL) {
       uint32_t gsel = key & 3;
       size_t region;
       uint32_t p0, p1 = 0;
@@ -1031,7 +1054,7 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   if (!rows) return SPGEMM_OK;
   TRY(ensure_rowinfo(ctx, B));
   ctx->plan.valid = false;
-  size_t need = 3 * align_up((size_t)rows * 4, 256) + align_up(rows, 256) + align_up((size_t)rows * 8, 256) + 1024 + NPROD_SLOTS * 8;
+  size_t need = 3 * align_up((size_t)rows * 4, 256) + 2 * align_up(rows, 256) + align_up((size_t)rows * 8, 256) + 1024 + NPROD_SLOTS * 8;
   const uint32_t max_long = rows;
   need += align_up((size_t)max_long * 4, 256);
   TRY(grow(ctx, ctx->arena, need));
@@ -1044,7 +1067,8 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   uint64_t *total = ar.take<uint64_t>(NPROD_SLOTS);
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
   HIP_TRY(hipMemsetAsync(total, 0, NPROD_SLOTS * 8, ctx->stream));
-  AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count};
+  uint8_t *same = ar.take<uint8_t>(rows);
+  AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count, same};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   hipLaunchKernelGGL(k_analyze_long, dim3(256), dim3(256), 0, ctx->stream, A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp);
