@@ -585,63 +585,114 @@ template <class T> __device__ __forceinline__ const_as_ptr<T> scalar_view(const 
 }
 
 // f(col, bval, aval, apos): apos = position of the A entry inside its row (wave-uniform).
-template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, class F>
-__device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
-  const auto a_ptr = scalar_view(A.ptr);
+//
+// The walk is software-pipelined over groups of PF A entries: while group g is consumed from
+// registers, the vector loads of group g+1 are in flight and the scalar loads of group g+2 (A
+// entries, then B row bounds) have been issued, so neither latency is exposed.
+template <bool WITH_AVAL> struct WalkInfo {
+  uint64_t p0[PF];   // start of the B row in B.col / B.val
+  uint32_t len[PF];  // entries of the B row (0 past the end of the A row)
+  double av[PF];     // value of the A entry
+};
+
+template <bool WITH_AVAL>
+__device__ __forceinline__ void walk_scalar_stage(const Csr &A, const Csr &B, uint64_t ka, uint64_t a1,
+                                                  WalkInfo<WITH_AVAL> &s) {
   const auto a_col = scalar_view(A.col);
   const auto a_val = scalar_view(A.val);
   const auto b_ptr = scalar_view(B.ptr);
-  const uint64_t a0 = a_ptr[row], a1 = a_ptr[row + 1];
-  for (uint64_t ka = a0; ka < a1; ka += PF) {
-    uint32_t len[PF], k[PF];
-    const uint32_t *pc[PF];
-    const double *pv[PF];
-    double av[PF];
-    uint64_t p0[PF], p1[PF];
-    // stage 1: PF A entries (independent scalar loads; the last group re-reads the row's last entry)
-    if (ka + PF <= a1) {
+  if (ka >= a1) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        k[u] = a_col[ka + u];
-        if constexpr (WITH_AVAL) av[u] = a_val[ka + u];
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const uint64_t kk = min(ka + u, a1 - 1);
-        k[u] = a_col[kk];
-        if constexpr (WITH_AVAL) av[u] = a_val[kk];
-      }
-    }
-    // stage 2: bounds of the PF B rows
+    for (int u = 0; u < PF; ++u) { s.len[u] = 0; s.p0[u] = 0; s.av[u] = 0.0; }
+    return;
+  }
+  uint32_t k[PF];
+  if (ka + PF <= a1) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      p0[u] = b_ptr[k[u]];
-      p1[u] = b_ptr[k[u] + 1];
+      k[u] = a_col[ka + u];
+      if constexpr (WITH_AVAL) s.av[u] = a_val[ka + u];
     }
+  } else { // the last group re-reads the row's last entry for its missing slots
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      len[u] = (ka + u < a1) ? (uint32_t)(p1[u] - p0[u]) : 0u;
-      pc[u] = B.col + p0[u];
-      pv[u] = B.val + p0[u];
-    }
-    uint32_t c[PF];
-    double v[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const bool ok = lane < len[u];
-      c[u] = ok ? pc[u][lane] : EMPTY_KEY;
-      if constexpr (WITH_VAL) v[u] = ok ? pv[u][lane] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const uint32_t apos = (uint32_t)(ka - a0) + u;
-      if (c[u] != EMPTY_KEY) f(c[u], WITH_VAL ? v[u] : 0.0, WITH_AVAL ? av[u] : 0.0, apos);
-      if (len[u] > 64) // wave-uniform
-        for (uint32_t j = 64 + lane; j < len[u]; j += 64)
-          f(pc[u][j], WITH_VAL ? pv[u][j] : 0.0, WITH_AVAL ? av[u] : 0.0, apos);
+      const uint64_t kk = min(ka + u, a1 - 1);
+      k[u] = a_col[kk];
+      if constexpr (WITH_AVAL) s.av[u] = a_val[kk];
     }
   }
+  uint64_t p1[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    s.p0[u] = b_ptr[k[u]];
+    p1[u] = b_ptr[k[u] + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < PF; ++u) s.len[u] = (ka + u < a1) ? (uint32_t)(p1[u] - s.p0[u]) : 0u;
+}
+
+template <bool WITH_VAL, bool WITH_AVAL>
+__device__ __forceinline__ void walk_vector_stage(const Csr &B, const WalkInfo<WITH_AVAL> &s, uint32_t lane,
+                                                  uint32_t (&c)[PF], double (&v)[PF]) {
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const bool ok = lane < s.len[u];
+    c[u] = ok ? (B.col + s.p0[u])[lane] : EMPTY_KEY;
+    if constexpr (WITH_VAL) v[u] = ok ? (B.val + s.p0[u])[lane] : 0.0;
+  }
+}
+
+// begin() issues the first loads of the walk (two scalar stages and one vector stage) so that a
+// kernel can overlap them with its LDS set-up; run() consumes the row.
+template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL> struct RowWalk {
+  uint64_t a0, a1;
+  WalkInfo<WITH_AVAL> s_cur, s_next;
+  uint32_t c_cur[PF];
+  double v_cur[PF];
+
+  __device__ __forceinline__ void begin(const Csr &A, const Csr &B, uint32_t row, uint32_t lane) {
+    const auto a_ptr = scalar_view(A.ptr);
+    a0 = a_ptr[row];
+    a1 = a_ptr[row + 1];
+    walk_scalar_stage<WITH_AVAL>(A, B, a0, a1, s_cur);
+    walk_vector_stage<WITH_VAL, WITH_AVAL>(B, s_cur, lane, c_cur, v_cur);
+    walk_scalar_stage<WITH_AVAL>(A, B, a0 + PF, a1, s_next);
+  }
+
+  template <class F> __device__ __forceinline__ void run(const Csr &A, const Csr &B, uint32_t lane, F f) {
+    WalkInfo<WITH_AVAL> s_after;
+    uint32_t c_next[PF];
+    double v_next[PF];
+    for (uint64_t ka = a0; ka < a1; ka += PF) {
+      walk_vector_stage<WITH_VAL, WITH_AVAL>(B, s_next, lane, c_next, v_next);
+      walk_scalar_stage<WITH_AVAL>(A, B, ka + 2 * PF, a1, s_after);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const uint32_t apos = (uint32_t)(ka - a0) + u;
+        if (c_cur[u] != EMPTY_KEY) f(c_cur[u], WITH_VAL ? v_cur[u] : 0.0, WITH_AVAL ? s_cur.av[u] : 0.0, apos);
+        if (s_cur.len[u] > 64) { // wave-uniform: the rest of a long B row, before the next A entry
+          const uint32_t *pc = B.col + s_cur.p0[u];
+          const double *pv = B.val + s_cur.p0[u];
+          for (uint32_t j = 64 + lane; j < s_cur.len[u]; j += 64)
+            f(pc[j], WITH_VAL ? pv[j] : 0.0, WITH_AVAL ? s_cur.av[u] : 0.0, apos);
+        }
+      }
+      s_cur = s_next;
+      s_next = s_after;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        c_cur[u] = c_next[u];
+        v_cur[u] = v_next[u];
+      }
+    }
+  }
+};
+
+template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, class F>
+__device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
+  RowWalk<WITH_VAL, WITH_AVAL> w;
+  w.begin(A, B, row, lane);
+  w.run(A, B, lane, f);
 }
 
 // Order-free walk (symbolic): the whole wavefront takes one A entry at a time, lanes over the B
@@ -1041,23 +1092,38 @@ __global__ void __launch_bounds__(256)
   uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
   double *vals = reinterpret_cast<double *>(bmp + words);
   double *avals = vals + (size_t)GRP_MAX * cap;
-  const uint32_t row = rows[idx];
-  const uint32_t cnt = min((uint32_t)m.gcnt[row], GRP_MAX);
-  const uint32_t base = m.cmin[row] & ~31u;
-  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
-  const uint32_t n = m.nnz[row];
-  const uint32_t *tin = m.temp_cols + m.t_off[row];
-  const uint32_t len_a = (uint32_t)(A.ptr[row + 1] - A.ptr[row]);
+  // row state through the scalar unit (all of it was written by earlier kernels)
+  const uint32_t row = scalar_view(rows)[idx];
+  const uint32_t cnt = min((uint32_t)scalar_view(m.gcnt)[row], GRP_MAX);
+  const uint32_t base = scalar_view(m.cmin)[row] & ~31u;
+  const uint32_t nw = ((scalar_view(m.cmax)[row] - base) >> 5) + 1u;
+  const uint32_t n = scalar_view((const uint32_t *)m.nnz)[row];
+  const uint32_t *tin = m.temp_cols + scalar_view(m.t_off)[row];
+  // first loads of the B walk, overlapped with the LDS set-up below
+  RowWalk<true, false> walk;
+  walk.begin(A, B, row, lane);
+  const uint32_t len_a = (uint32_t)(walk.a1 - walk.a0);
+  // lane j holds the output offset and the A offset of the group's j-th row
+  uint64_t my_off = 0, my_a = 0;
+  if (lane < cnt) {
+    my_off = o.c_ptr[row + lane];
+    my_a = A.ptr[row + lane];
+  }
   for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
-  for (uint32_t j = 0; j < cnt; ++j) {
-    for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
-    const double *av = A.val + A.ptr[row + j];
-    for (uint32_t t = lane; t < len_a && t < GRP_ALEN; t += 64) avals[j * GRP_ALEN + t] = av[t];
+#pragma unroll
+  for (uint32_t j = 0; j < GRP_MAX; ++j) {
+    if (j < cnt) {
+      for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
+      const double *av = A.val + readlane64(my_a, j);
+      for (uint32_t t = lane; t < len_a && t < GRP_ALEN; t += 64) avals[j * GRP_ALEN + t] = av[t];
+    }
   }
   lds_fence();
   for (uint32_t p = lane; p < n; p += 64) {
     uint32_t c = tin[p];
-    for (uint32_t j = 0; j < cnt; ++j) o.c_col[o.c_ptr[row + j] + p] = c;
+#pragma unroll
+    for (uint32_t j = 0; j < GRP_MAX; ++j)
+      if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
     uint32_t cc = c - base;
     atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
   }
@@ -1071,7 +1137,7 @@ __global__ void __launch_bounds__(256)
     carry += group_last<64>(incl);
   }
   lds_fence();
-  wave_row_walk<true, false>(A, B, row, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
+  walk.run(A, B, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
     uint32_t cc = c - base;
     uint64_t e = bmp[cc >> 5];
     uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
@@ -1079,12 +1145,15 @@ __global__ void __launch_bounds__(256)
   });
   lds_fence();
   uint32_t nz = 0;
-  for (uint32_t j = 0; j < cnt; ++j) {
-    const uint64_t off = o.c_ptr[row + j];
-    for (uint32_t p = lane; p < n; p += 64) {
-      double v = vals[j * cap + p];
-      o.c_val[off + p] = v;
-      nz += (v == 0.0) ? 1u : 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < GRP_MAX; ++j) {
+    if (j < cnt) {
+      const uint64_t off = readlane64(my_off, j);
+      for (uint32_t p = lane; p < n; p += 64) {
+        double v = vals[j * cap + p];
+        o.c_val[off + p] = v;
+        nz += (v == 0.0) ? 1u : 0u;
+      }
     }
   }
   nz = group_sum<64>(nz);
