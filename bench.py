@@ -50,6 +50,19 @@ def make_workload(args):
     return A, name
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this workload
+    (profiles/*_traffic_<workload>.json, made by tools/prof_all.sh + tools/make_traffic.py: separate
+    rocprofv3 --pmc passes, read side rebuilt from the per-size request counters because FETCH_SIZE
+    tallies 128-B requests at 64 B on gfx950).  None when no profile is committed for it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_traffic_{workload}.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"].get(kernel)
+    return None if k is None else k["hbm_bytes"]
+
+
 def algorithmic_bytes(nnz_a, nprod, nnz_c, rows):
     """Row-wise Gustavson traffic model: every A entry, every product's B entry and every C
     entry moves once as {u32 index, f64 value}; plus the A (u32) and C (u64) row pointers."""
@@ -124,10 +137,10 @@ def run_single(args):
     if dom:
         b = algorithmic_bytes(dom["nnz_a"], dom["nprod"], dom["nnz_c"], dom["rows"])
         achieved = b / (dom["ms"] * 1e-3) / 1e9
+        kname = "k_num_window_grp" if dom["path"] == "window_groups" else f"k_num_{dom['path']}<{dom['lanes']}>"
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "k_num_window_grp" if dom["path"] == "window_groups" else f"k_num_{dom['path']}<{dom['lanes']}>",
-                    "kernel_ms": dom["ms"],
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, kname),
+                    "kernel": kname, "kernel_ms": dom["ms"],
                     "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b}
     b_all = st["bytes_algorithmic"]
     gflops = 2.0 * st["nprod"] / (ms_per_step * 1e-3) / 1e9
