@@ -695,39 +695,88 @@ __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32
   w.run(A, B, lane, f);
 }
 
-// Order-free walk (symbolic): the whole wavefront takes one A entry at a time, lanes over the B
-// row; the loads of PF consecutive B rows are issued back to back so their latencies overlap.
-template <class F>
-__device__ __forceinline__ void wave_for_each_col(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
-  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+// ---- flat walk ---------------------------------------------------------------------------------
+// For rows whose B rows are short, one A entry per step leaves most lanes idle.  The flat walk
+// lays the products of up to 64 A entries end to end (A order, then B row order) and hands 64
+// consecutive products to the 64 lanes per step, whatever B rows they come from: lane l of a step
+// holds product q = q0 + l and finds its A entry by a binary search over the exclusive prefix
+// sums of the B row lengths (kept in LDS).  Products of one step are in CPU order by lane, and
+// steps are sequential, so a consumer that resolves two lanes hitting one accumulator in lane
+// order (claim_in_lane_order) still adds in the CPU order.
+// LDS scratch per wavefront: st[64] u32 | p0s[64] u64 | avs[64] f64 = FLAT_BYTES.
+// f(col, bval, aval, apos) is called by ALL lanes every step; col == EMPTY_KEY marks an idle lane.
+constexpr uint32_t FLAT_BYTES = 1280;
+
+template <bool WITH_VAL, class F>
+__device__ __forceinline__ void flat_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane,
+                                          unsigned char *scratch, F f) {
+  uint32_t *st = reinterpret_cast<uint32_t *>(scratch);
+  uint64_t *p0s = reinterpret_cast<uint64_t *>(scratch + 256);
+  double *avs = reinterpret_cast<double *>(scratch + 768);
+  const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
   for (uint64_t ab = a0; ab < a1; ab += 64) {
     const uint64_t ka = ab + lane;
-    uint64_t b0 = 0, b1 = 0;
+    uint32_t len = 0;
+    uint64_t p0 = 0;
+    double av = 0.0;
     if (ka < a1) {
-      uint32_t k = A.col[ka];
-      b0 = B.ptr[k];
-      b1 = B.ptr[k + 1];
+      const uint32_t k = A.col[ka];
+      p0 = B.ptr[k];
+      len = (uint32_t)(B.ptr[k + 1] - p0);
+      if constexpr (WITH_VAL) av = A.val[ka];
     }
-    const uint32_t cnt = (uint32_t)min((uint64_t)64, a1 - ab);
-    for (uint32_t t = 0; t < cnt; t += PF) {
-      uint32_t c[PF];
-      uint64_t s[PF], e[PF];
+    const uint32_t incl = group_incl_scan<64>(len);
+    const uint32_t total = group_last<64>(incl);
+    lds_fence(); // the previous chunk has been consumed
+    st[lane] = incl - len;
+    p0s[lane] = p0;
+    if constexpr (WITH_VAL) avs[lane] = av;
+    lds_fence();
+    auto fetch = [&](uint32_t q, uint32_t &t, uint32_t &c, double &bv) {
+      const bool valid = q < total;
+      const uint32_t qq = valid ? q : 0u;
+      t = 0;
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const uint32_t tt = min(t + u, 63u);
-        s[u] = readlane64(b0, tt);
-        e[u] = (t + u < cnt) ? readlane64(b1, tt) : s[u];
-        const uint64_t j = s[u] + lane;
-        c[u] = (j < e[u]) ? B.col[j] : EMPTY_KEY;
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u)
-        if (c[u] != EMPTY_KEY) f(c[u]);
-#pragma unroll
-      for (int u = 0; u < PF; ++u)
-        if (e[u] - s[u] > 64)
-          for (uint64_t j = s[u] + 64 + lane; j < e[u]; j += 64) f(B.col[j]);
+      for (uint32_t s = 32; s > 0; s >>= 1)
+        if (st[t + s] <= qq) t += s; // largest t with st[t] <= q: the entry that holds product q
+      const uint64_t p = p0s[t] + (qq - st[t]);
+      c = valid ? B.col[p] : EMPTY_KEY;
+      if constexpr (WITH_VAL) bv = valid ? B.val[p] : 0.0;
+    };
+    uint32_t t_cur = 0, c_cur = EMPTY_KEY;
+    double bv_cur = 0.0;
+    if (total) fetch(lane, t_cur, c_cur, bv_cur);
+    for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+      uint32_t t_n = 0, c_n = EMPTY_KEY;
+      double bv_n = 0.0;
+      if (q0 + 64 < total) fetch(q0 + 64 + lane, t_n, c_n, bv_n); // next step's loads fly during this step
+      double av_cur = 0.0;
+      if constexpr (WITH_VAL) av_cur = avs[t_cur];
+      f(c_cur, bv_cur, av_cur, (uint32_t)(ab - a0) + t_cur);
+      t_cur = t_n;
+      c_cur = c_n;
+      bv_cur = bv_n;
     }
+  }
+}
+
+// Add `prod` to vals[p] for every lane with pending == true so that lanes of this call that share
+// one p add in lane order.  owner[] (one uint32 per accumulator, zero at kernel start) takes
+// claims (stamp << 6 | 63 - lane) by atomic max: the lowest pending lane of the newest round wins
+// its accumulator, adds, and the others try again in the next round.  stamp is wave-uniform.
+__device__ __forceinline__ void claim_in_lane_order(double *vals, uint32_t *owner, uint32_t &stamp, uint32_t lane,
+                                                    bool pending, uint32_t p, double prod) {
+  for (;;) {
+    ++stamp;
+    const uint32_t tag = (stamp << 6) | (63u - lane);
+    if (pending) atomicMax(&owner[p], tag);
+    lds_fence();
+    if (pending && owner[p] == tag) {
+      lds_add_f64(&vals[p], prod);
+      pending = false;
+    }
+    if (!__any(pending)) break;
+    lds_fence();
   }
 }
 
@@ -750,6 +799,8 @@ __device__ __forceinline__ uint32_t select_bit(uint32_t bits, uint32_t r) {
 // same bitmap word and the LDS would serialise them.  Lanes first combine their bits inside
 // each 16-lane row (an OR-scan over lanes that share the word), and only the last lane of every
 // run issues the LDS atomic.
+// FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
+template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                  uint32_t words) {
@@ -758,16 +809,20 @@ __global__ void __launch_bounds__(256)
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform on the scalar unit
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (idx >= nrows) return;
-  uint32_t *bm = reinterpret_cast<uint32_t *>(smem) + (size_t)w * words * 2u;
+  const size_t region = (size_t)words * 8u + (FLAT ? FLAT_BYTES : 0u);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);
   const uint32_t row = rows[idx];
   const uint32_t base = m.cmin[row] & ~31u;
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
   for (uint32_t i = lane; i < nw; i += 64) reinterpret_cast<uint64_t *>(bm)[i] = 0ull;
   lds_fence();
-  wave_row_walk<false>(A, B, row, lane, [&](uint32_t col, double, double, uint32_t) {
+  auto mark = [&](uint32_t col, double, double, uint32_t) {
+    if (col == EMPTY_KEY) return;
     uint32_t c = col - base;
     atomicOr(&bm[(c >> 5) * 2u], 1u << (c & 31u));
-  });
+  };
+  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)words * 8u, mark);
+  else wave_row_walk<false>(A, B, row, lane, mark);
   lds_fence();
 #if !SG_SYM_ENUM_SEARCH
   uint32_t *out = m.temp_cols + m.t_off[row];
@@ -827,6 +882,7 @@ __global__ void __launch_bounds__(256)
 // S >= 2 * nprod, so the table is at most half full.  Sorting is a bucket rank sort: a monotone
 // map of the column into S/2 buckets, counting sort into bucket order, then each key finds its
 // rank among the (few) keys of its bucket.
+template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_sym_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                uint32_t log2s) {
@@ -836,7 +892,8 @@ __global__ void __launch_bounds__(256)
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (idx >= nrows) return;
   const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
-  uint32_t *keys = reinterpret_cast<uint32_t *>(smem) + (size_t)w * (2u * S);
+  const size_t region = (size_t)S * 8u + (FLAT ? FLAT_BYTES : 0u);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
   uint32_t *cnt = keys + S;
   uint32_t *tk = cnt + NB;
   const uint32_t row = rows[idx];
@@ -844,7 +901,8 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
   lds_fence();
   uint32_t mine = 0;
-  wave_row_walk<false>(A, B, row, lane, [&](uint32_t c, double, double, uint32_t) {
+  auto insert = [&](uint32_t c, double, double, uint32_t) {
+    if (c == EMPTY_KEY) return;
     uint32_t h = hash_slot(c, log2s);
     for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
       uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
@@ -852,7 +910,9 @@ __global__ void __launch_bounds__(256)
       if (old == c) break;
       h = (h + 1u) & mask;
     }
-  });
+  };
+  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)S * 8u, insert);
+  else wave_row_walk<false>(A, B, row, lane, insert);
   lds_fence();
   const uint32_t n = group_sum<64>(mine);
   const uint32_t cmin = m.cmin[row];
@@ -960,84 +1020,36 @@ struct NumOut {
   unsigned long long *zero_count; // entries whose accumulated value is exactly 0.0
 };
 
-// Walk the products of `row` in the CPU order and call acc(col, product).
-// The group preloads G A entries (value, B row bounds) at a time, then visits them one by one;
-// for one A entry the G lanes take consecutive entries of the B row.  The first G entries of PF
-// consecutive B rows are fetched back to back (their latencies overlap) and consumed strictly in
-// A order, each B row completely before the next one.
-template <int G, class F>
-__device__ __forceinline__ void for_each_product(const Csr &A, const Csr &B, uint32_t row, uint32_t lg, F acc) {
-  const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
-  for (uint64_t ab = a0; ab < a1; ab += G) {
-    uint64_t ka = ab + lg;
-    double av = 0.0;
-    uint64_t b0 = 0, b1 = 0;
-    if (ka < a1) {
-      uint32_t k = A.col[ka];
-      av = A.val[ka];
-      b0 = B.ptr[k];
-      b1 = B.ptr[k + 1];
-    }
-    const uint32_t cnt = (uint32_t)min((uint64_t)G, a1 - ab);
-    for (uint32_t t = 0; t < cnt; t += PF) {
-      uint32_t c[PF];
-      double v[PF], avt[PF];
-      uint64_t s[PF], e[PF];
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const uint32_t tt = min(t + u, (uint32_t)(G - 1));
-        if constexpr (G == 64) {
-          s[u] = readlane64(b0, tt);
-          e[u] = readlane64(b1, tt);
-          avt[u] = readlane_f64(av, tt);
-        } else {
-          s[u] = __shfl(b0, tt, G);
-          e[u] = __shfl(b1, tt, G);
-          avt[u] = __shfl(av, tt, G);
-        }
-        if (t + u >= cnt) e[u] = s[u];
-        const uint64_t j = s[u] + lg;
-        const bool ok = j < e[u];
-        c[u] = ok ? B.col[j] : EMPTY_KEY;
-        v[u] = ok ? B.val[j] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        if (c[u] != EMPTY_KEY) acc(c[u], __dmul_rn(avt[u], v[u]));
-        if (e[u] - s[u] > G)
-          for (uint64_t j = s[u] + G + lg; j < e[u]; j += G) acc(B.col[j], __dmul_rn(avt[u], B.val[j]));
-      }
-    }
-  }
-}
-
-// numeric, window path: G lanes per row.
-// LDS per group: bmp[words] of {lo: bitmap word, hi: number of set bits before the word}
-//                | vals[cap] doubles.
-template <int G>
+// numeric, window path: one wavefront per row.
+// LDS per wavefront: bmp[words] of {lo: bitmap word, hi: number of set bits before the word}
+//                    | vals[cap] doubles | FLAT only: owner[cap] uint32 + flat-walk scratch.
+template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_num_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-                 uint32_t words, uint32_t cap, uint32_t gpb) {
+                 uint32_t words, uint32_t cap, uint32_t wpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lg = threadIdx.x & (G - 1);
-  uint32_t gid = threadIdx.x / G;
-  if constexpr (G == 64) gid = __builtin_amdgcn_readfirstlane(gid); // one row per wavefront: scalar row state
-  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
-  if (gid >= gpb || idx >= nrows) return;
-  const size_t region = (size_t)words * 8u + (size_t)cap * 8u;
-  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + gid * region);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // one row per wavefront: scalar row state
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (size_t)cap * 8u + (FLAT ? (size_t)cap * 4u + FLAT_BYTES : 0u);
+  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
   uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
   double *vals = reinterpret_cast<double *>(bmp + words);
+  uint32_t *owner = reinterpret_cast<uint32_t *>(vals + cap);
   const uint32_t row = rows[idx];
   const uint32_t base = m.cmin[row] & ~31u;
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
   const uint32_t n = m.nnz[row];
   const uint64_t off = o.c_ptr[row];
   const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
-  for (uint32_t i = lg; i < nw; i += G) bmp[i] = 0ull;
-  for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
+  for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
+  for (uint32_t i = lane; i < n; i += 64) {
+    vals[i] = 0.0;
+    if constexpr (FLAT) owner[i] = 0u;
+  }
   lds_fence();
-  for (uint32_t p = lg; p < n; p += G) {
+  for (uint32_t p = lane; p < n; p += 64) {
     uint32_t c = tin[p];
     o.c_col[off + p] = c;
     uint32_t cc = c - base;
@@ -1045,33 +1057,42 @@ __global__ void __launch_bounds__(256)
   }
   lds_fence();
   uint32_t carry = 0;
-  for (uint32_t r0 = 0; r0 < nw; r0 += G) {
-    uint32_t wi = r0 + lg;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
     uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
-    uint32_t incl = group_incl_scan<G>(pc);
+    uint32_t incl = group_incl_scan<64>(pc);
     if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
-    carry += group_last<G>(incl);
+    carry += group_last<64>(incl);
   }
   lds_fence();
-  auto acc = [&](uint32_t c, double p) {
+  auto position = [&](uint32_t c) {
     uint32_t cc = c - base;
     uint64_t e = bmp[cc >> 5];
-    uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
-    if (pos < n) lds_add_f64(&vals[pos], p);
+    return (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
   };
-  if constexpr (G == 64)
-    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av, uint32_t) { acc(c, __dmul_rn(av, bv)); });
-  else
-    for_each_product<G>(A, B, row, lg, acc);
+  if constexpr (FLAT) {
+    uint32_t stamp = 0;
+    flat_walk<true>(A, B, row, lane, reinterpret_cast<unsigned char *>(owner + cap),
+                    [&](uint32_t c, double bv, double av, uint32_t) {
+                      const bool live = c != EMPTY_KEY;
+                      const uint32_t pos = live ? position(c) : 0u;
+                      claim_in_lane_order(vals, owner, stamp, lane, live && pos < n, pos, __dmul_rn(av, bv));
+                    });
+  } else {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t pos = position(c);
+      if (pos < n) lds_add_f64(&vals[pos], __dmul_rn(av, bv));
+    });
+  }
   lds_fence();
   uint32_t nz = 0;
-  for (uint32_t p = lg; p < n; p += G) {
+  for (uint32_t p = lane; p < n; p += 64) {
     double v = vals[p];
     o.c_val[off + p] = v;
     nz += (v == 0.0) ? 1u : 0u;
   }
-  nz = group_sum<G>(nz);
-  if (lg == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
 
 // numeric, window path, row groups: one wavefront per group of up to GRP_MAX consecutive rows of
@@ -1160,34 +1181,38 @@ __global__ void __launch_bounds__(256)
   if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
 
-// numeric, hash path: G lanes per row.
-// LDS per group: keys[S] uint32 | pos[S] uint16 | vals[S/2] double = 10*S bytes; nnz <= S/2.
+// numeric, hash path: one wavefront per row.
+// LDS per wavefront: vals[S/2] double | keys[S] uint32 | pos[S] uint16 (= 10*S bytes; nnz <= S/2)
+//                    | FLAT only: owner[S/2] uint32 + flat-walk scratch.
 // The sorted structural columns are inserted first (slot -> output position), so the
 // accumulate loop only probes (no compare-and-swap) and the output needs no sort.
-template <int G>
+template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_num_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-               uint32_t log2s, uint32_t gpb) {
+               uint32_t log2s, uint32_t wpb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lg = threadIdx.x & (G - 1);
-  uint32_t gid = threadIdx.x / G;
-  if constexpr (G == 64) gid = __builtin_amdgcn_readfirstlane(gid);
-  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * gpb + gid;
-  if (gid >= gpb || idx >= nrows) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
   const uint32_t S = 1u << log2s, mask = S - 1u;
-  const size_t region = (size_t)S * 10u;
-  unsigned char *reg = smem + gid * region;
+  const size_t region = (size_t)S * 10u + (FLAT ? (size_t)S * 2u + FLAT_BYTES : 0u);
+  unsigned char *reg = smem + w * region;
   double *vals = reinterpret_cast<double *>(reg);                 // S/2 doubles = 4*S bytes
   uint32_t *keys = reinterpret_cast<uint32_t *>(reg + 4u * S);    // S uint32
   uint16_t *pos = reinterpret_cast<uint16_t *>(reg + 8u * S);     // S uint16
+  uint32_t *owner = reinterpret_cast<uint32_t *>(reg + 10u * S);  // S/2 uint32 (FLAT)
   const uint32_t row = rows[idx];
   const uint32_t n = m.nnz[row];
   const uint64_t off = o.c_ptr[row];
   const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
-  for (uint32_t i = lg; i < S; i += G) keys[i] = EMPTY_KEY;
-  for (uint32_t i = lg; i < n; i += G) vals[i] = 0.0;
+  for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
+  for (uint32_t i = lane; i < n; i += 64) {
+    vals[i] = 0.0;
+    if constexpr (FLAT) owner[i] = 0u;
+  }
   lds_fence();
-  for (uint32_t p = lg; p < n; p += G) {
+  for (uint32_t p = lane; p < n; p += 64) {
     uint32_t c = tin[p];
     o.c_col[off + p] = c;
     uint32_t h = hash_slot(c, log2s);
@@ -1196,25 +1221,35 @@ __global__ void __launch_bounds__(256)
     if (it < S) pos[h] = (uint16_t)p;
   }
   lds_fence();
-  auto acc = [&](uint32_t c, double p) {
+  // slot of column c (S when absent, which cannot happen for a consistent symbolic result)
+  auto find = [&](uint32_t c) {
     uint32_t h = hash_slot(c, log2s);
     uint32_t it = 0;
     while (keys[h] != c && it < S) { h = (h + 1u) & mask; ++it; }
-    if (it < S) lds_add_f64(&vals[pos[h]], p);
+    return it < S ? h : S;
   };
-  if constexpr (G == 64)
-    wave_row_walk<true>(A, B, row, lg, [&](uint32_t c, double bv, double av, uint32_t) { acc(c, __dmul_rn(av, bv)); });
-  else
-    for_each_product<G>(A, B, row, lg, acc);
+  if constexpr (FLAT) {
+    uint32_t stamp = 0;
+    flat_walk<true>(A, B, row, lane, reg + 12u * S, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t h = c != EMPTY_KEY ? find(c) : S;
+      const bool live = h < S;
+      claim_in_lane_order(vals, owner, stamp, lane, live, live ? (uint32_t)pos[h] : 0u, __dmul_rn(av, bv));
+    });
+  } else {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t h = find(c);
+      if (h < S) lds_add_f64(&vals[pos[h]], __dmul_rn(av, bv));
+    });
+  }
   lds_fence();
   uint32_t nz = 0;
-  for (uint32_t p = lg; p < n; p += G) {
+  for (uint32_t p = lane; p < n; p += 64) {
     double v = vals[p];
     o.c_val[off + p] = v;
     nz += (v == 0.0) ? 1u : 0u;
   }
-  nz = group_sum<G>(nz);
-  if (lg == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
 
 // numeric, global path: ONE wavefront per row (the k order must be kept), accumulating straight

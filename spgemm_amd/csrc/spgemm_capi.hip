@@ -75,6 +75,7 @@ struct spgemm_ctx {
   size_t lds_budget = 64 * 1024; // LDS bytes per workgroup aimed for (>= 2 workgroups per CU)
   uint32_t long_len = 2048;      // A rows longer than this are analysed by a whole workgroup
   uint32_t row_groups = 1;       // accumulate runs of identical A rows together
+  uint32_t flat_walk = 1;        // rows with short B rows: lay products end to end over the lanes
   uint32_t global_blocks_sym = 512;
   uint32_t global_blocks_num = 2048;
   Growable arena;     // per-multiply row arrays
@@ -242,19 +243,7 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   return SPGEMM_OK;
 }
 
-// ---- kernel dispatch by lane-group size ------------------------------------------------------------
-template <class... Args> struct Launcher {
-  template <void (*K8)(Args...), void (*K16)(Args...), void (*K32)(Args...), void (*K64)(Args...)>
-  static void go(uint32_t gsel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
-    switch (gsel) {
-    case 0: hipLaunchKernelGGL(K8, grid, block, lds, s, args...); break;
-    case 1: hipLaunchKernelGGL(K16, grid, block, lds, s, args...); break;
-    case 2: hipLaunchKernelGGL(K32, grid, block, lds, s, args...); break;
-    default: hipLaunchKernelGGL(K64, grid, block, lds, s, args...); break;
-    }
-  }
-};
-
+// ---- LDS limits ------------------------------------------------------------------------------------
 static bool g_attr_set = false;
 template <class K> static void raise_lds_limit(K kernel) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -262,13 +251,11 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() {
   if (g_attr_set) return;
-  raise_lds_limit(k_sym_window);
+  raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
   raise_lds_limit(k_num_window_grp);
-  raise_lds_limit(k_sym_hash);
-  raise_lds_limit(k_num_window<8>); raise_lds_limit(k_num_window<16>);
-  raise_lds_limit(k_num_window<32>); raise_lds_limit(k_num_window<64>);
-  raise_lds_limit(k_num_hash<8>); raise_lds_limit(k_num_hash<16>);
-  raise_lds_limit(k_num_hash<32>); raise_lds_limit(k_num_hash<64>);
+  raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
+  raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
+  raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
   g_attr_set = true;
 }
 
@@ -396,6 +383,8 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "lds_budget") {
     if (value < 8192 || value > 160 * 1024) return fail(SPGEMM_ERR_INVALID, "lds_budget must be 8192..163840");
     ctx->lds_budget = (size_t)value;
+  } else if (n == "flat_walk") {
+    ctx->flat_walk = value != 0;
   } else if (n == "row_groups") {
     ctx->row_groups = value != 0;
   } else if (n == "profile_launches") {
@@ -593,7 +582,6 @@ struct HostCounts {
 };
 static_assert(sizeof(HostCounts) <= PINNED_BYTES, "pinned staging buffer too small");
 
-static uint32_t threads_for(uint32_t groups, uint32_t G) { return (uint32_t)align_up((size_t)groups * G, 64); }
 
 // symbolic phase: analysis, binning, per-bin symbolic kernels, scan of the row counts.
 // On success ctx->plan describes the row arrays (in ctx->arena) and d_row_ptr holds the
@@ -698,21 +686,23 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     if (key < SYM_HASH0) {
       uint32_t tier = key >> 2;
       uint32_t words = (64u << tier) + 2u;
-      size_t region = (size_t)words * 8;
+      const bool flat = (key & 3) < 3 && ctx->flat_walk; // short B rows: products laid end to end over the lanes
+      size_t region = (size_t)words * 8 + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = 4;
       st.rows_window += cnt;
-      TRY(prof_begin(ctx, 0, 0, 64, cnt, words, 0, region * wpb, rows_bin));
-      hipLaunchKernelGGL(k_sym_window, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
-                         cnt, cA, cB, rm, words);
+      TRY(prof_begin(ctx, 0, 0, flat ? 0 : 64, cnt, words, 0, region * wpb, rows_bin));
+      hipLaunchKernelGGL(flat ? k_sym_window<true> : k_sym_window<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
+                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
       uint32_t log2s = 7 + 2 * tier;
-      size_t region = (size_t)8 << log2s;
+      const bool flat = (key & 3) < 3 && ctx->flat_walk;
+      size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
       st.rows_hash += cnt;
-      TRY(prof_begin(ctx, 0, 1, 64, cnt, log2s, 0, region * wpb, rows_bin));
-      hipLaunchKernelGGL(k_sym_hash, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
-                         cnt, cA, cB, rm, log2s);
+      TRY(prof_begin(ctx, 0, 1, flat ? 0 : 64, cnt, log2s, 0, region * wpb, rows_bin));
+      hipLaunchKernelGGL(flat ? k_sym_hash<true> : k_sym_hash<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
+                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
@@ -792,42 +782,31 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       hipLaunchKernelGGL(k_num_window_grp, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
                          cnt, cA, cB, rm, no, words, cap, wpb);
     } else if (key < NUM_GLOBAL) {
-      uint32_t gsel = key & 3;
+      const bool flat = (key & 3) < 3 && ctx->flat_walk;
+      const bool window = key < NUM_HASH0;
       size_t region;
       uint32_t p0, p1 = 0;
-      bool window = key < NUM_HASH0;
       if (window) {
         uint32_t st_ = (key >> 2) >> 2, ct = (key >> 2) & 3;
         p0 = (64u << st_) + 2u;   // words
         p1 = 128u << (2 * ct);    // cap
-        region = (size_t)p0 * 8 + (size_t)p1 * 8;
+        region = (size_t)p0 * 8 + (size_t)p1 * 8 + (flat ? (size_t)p1 * 4 + FLAT_BYTES : 0);
       } else {
         uint32_t ct = ((key - NUM_HASH0) >> 2) & 3;
         p0 = 7 + 2 * ct;          // log2 S
-        region = (size_t)10 << p0;
+        region = ((size_t)10 << p0) + (flat ? ((size_t)2 << p0) + FLAT_BYTES : 0);
       }
-      // Lanes per row: the requested group size, widened while one wavefront's groups would
-      // not fit the LDS of a workgroup.
-      while (gsel < 3 && (64u >> (3 + gsel)) * region > lds_max) ++gsel;
-      uint32_t G = 8u << gsel;
-      uint32_t gpb = (uint32_t)std::min<size_t>(256 / G, std::max<size_t>(1, ctx->lds_budget / region));
-      if ((size_t)gpb * region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
-      // use whole wavefronts: round the group count up to fill the last wavefront when it fits
-      uint32_t per_wave = 64 / G;
-      if (gpb % per_wave && (size_t)(gpb / per_wave + 1) * per_wave * region <= lds_max) gpb = (gpb / per_wave + 1) * per_wave;
-      gpb = std::min<uint32_t>(gpb, 256 / G);
-      dim3 grid(div_up_u64(cnt, gpb)), block(threads_for(gpb, G));
-      size_t lds = (size_t)gpb * region;
-      TRY(prof_begin(ctx, 1, window ? 0 : 1, G, cnt, p0, p1, lds, rows_bin));
-      if (window) {
-        Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, NumOut, uint32_t, uint32_t, uint32_t>::go<
-            k_num_window<8>, k_num_window<16>, k_num_window<32>, k_num_window<64>>(gsel, grid, block, lds, ctx->stream,
-                                                                                  rows_bin, cnt, cA, cB, rm, no, p0, p1, gpb);
-      } else {
-        Launcher<const uint32_t *, uint32_t, Csr, Csr, RowMeta, NumOut, uint32_t, uint32_t>::go<
-            k_num_hash<8>, k_num_hash<16>, k_num_hash<32>, k_num_hash<64>>(gsel, grid, block, lds, ctx->stream, rows_bin,
-                                                                          cnt, cA, cB, rm, no, p0, gpb);
-      }
+      if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
+      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      dim3 grid(div_up_u64(cnt, wpb)), block(64 * wpb);
+      size_t lds = (size_t)wpb * region;
+      TRY(prof_begin(ctx, 1, window ? 0 : 1, flat ? 0 : 64, cnt, p0, p1, lds, rows_bin));
+      if (window)
+        hipLaunchKernelGGL(flat ? k_num_window<true> : k_num_window<false>, grid, block, lds, ctx->stream, rows_bin, cnt,
+                           cA, cB, rm, no, p0, p1, wpb);
+      else
+        hipLaunchKernelGGL(flat ? k_num_hash<true> : k_num_hash<false>, grid, block, lds, ctx->stream, rows_bin, cnt, cA,
+                           cB, rm, no, p0, wpb);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
