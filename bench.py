@@ -101,6 +101,9 @@ def run_single(args):
     ctx = capi.Context(0)
     dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
     ctx.set_option("profile_launches", 1)
+    for o in args.opt:
+        name, value = o.split("=")
+        ctx.set_option(name, int(value))
     for _ in range(args.warmup):
         ctx.multiply(dA, dA).free()
     ctx.synchronize()
@@ -179,6 +182,8 @@ def main():
                     help="distributed variant (N > 1): all sections, bitmap-filtered sections, "
                          "or random row/column shuffle + bitmap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option (spgemm_set_option), e.g. --opt row_groups=0")
     ap.add_argument("--dist", action="store_true",
                     help="use the distributed operator even at N = 1 (rehearsal of the N > 1 path)")
     args = ap.parse_args()
