@@ -23,16 +23,19 @@ constexpr uint32_t KEY_NONE = 255u; // row needs no kernel (no products)
 
 // ---- bin keys ------------------------------------------------------------------------------
 // symbolic:  [0,24)  window, key = span_tier*4 + gsel, span <= 2048 << span_tier
-//            [24,40) hash,   key = 24 + tier*4 + gsel, nprod <= 64 << (2*tier)
-//            [40,44) global, key = 40 + gsel
+//            [24,52) hash,   key = 24 + tier*4 + gsel, nprod <= 64 << tier (table of 128 << tier slots)
+//            [52,56) global, key = 52 + gsel
 // numeric:   [0,96)   window, key = (span_tier*4 + cap_tier)*4 + gsel, nnz <= 128 << (2*cap_tier)
-//            [96,112) hash,   key = 96 + cap_tier*4 + gsel,             nnz <= 64 << (2*cap_tier)
-//            112      global
-//            [113,137) window, row groups: key = 113 + span_tier*4 + cap_tier (one wavefront per group
+//            [96,124) hash,   key = 96 + tier*4 + gsel,                 nnz <= 64 << tier
+//            124      global
+//            [125,149) window, row groups: key = 125 + span_tier*4 + cap_tier (one wavefront per group
 //                      of up to GRP_MAX consecutive rows of A with identical column lists)
-constexpr int SYM_WIN0 = 0, SYM_HASH0 = 24, SYM_GLOBAL0 = 40, SYM_NBINS = 44;
-constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = 112, NUM_GRP0 = 113, NUM_NBINS = 137;
+constexpr int HASH_TIERS = 7; // table sizes 128 << tier
+constexpr int SYM_WIN0 = 0, SYM_HASH0 = 24, SYM_GLOBAL0 = SYM_HASH0 + 4 * HASH_TIERS, SYM_NBINS = SYM_GLOBAL0 + 4;
+constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = NUM_HASH0 + 4 * HASH_TIERS, NUM_GRP0 = NUM_GLOBAL + 1,
+              NUM_NBINS = NUM_GRP0 + 24;
 constexpr int MAX_BINS = 192;
+static_assert(NUM_NBINS <= MAX_BINS && NUM_NBINS < 255, "bin keys are 8 bit");
 constexpr uint32_t GRP_MAX = 8;   // rows per group
 constexpr uint32_t GRP_ALEN = 64; // longest A row that is grouped (its values are staged in LDS)
 
@@ -63,7 +66,7 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
     return SYM_WIN0 + t * 4 + g;
   }
   if (nprod <= p.hash_max_nprod) {
-    uint32_t t = nprod <= 64 ? 0u : nprod <= 256 ? 1u : nprod <= 1024 ? 2u : 3u;
+    uint32_t t = ceil_log2_u32(nprod < 64u ? 64u : (uint32_t)nprod) - 6u; // nprod <= 64 << t
     return SYM_HASH0 + t * 4 + g;
   }
   return SYM_GLOBAL0 + g;
@@ -82,7 +85,7 @@ __host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, u
     return NUM_GLOBAL;
   }
   if (nnz <= 4096u) {
-    uint32_t ct = nnz <= 64 ? 0u : nnz <= 256 ? 1u : nnz <= 1024 ? 2u : 3u;
+    uint32_t ct = ceil_log2_u32(nnz < 64u ? 64u : nnz) - 6u; // nnz <= 64 << ct
     return NUM_HASH0 + ct * 4 + g;
   }
   return NUM_GLOBAL;

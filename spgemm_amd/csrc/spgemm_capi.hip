@@ -695,7 +695,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
-      uint32_t log2s = 7 + 2 * tier;
+      uint32_t log2s = 7 + tier;
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
@@ -792,8 +792,8 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
         p1 = 128u << (2 * ct);    // cap
         region = (size_t)p0 * 8 + (size_t)p1 * 8 + (flat ? (size_t)p1 * 4 + FLAT_BYTES : 0);
       } else {
-        uint32_t ct = ((key - NUM_HASH0) >> 2) & 3;
-        p0 = 7 + 2 * ct;          // log2 S
+        uint32_t ct = (uint32_t)(key - NUM_HASH0) >> 2;
+        p0 = 7 + ct;              // log2 S
         region = ((size_t)10 << p0) + (flat ? ((size_t)2 << p0) + FLAT_BYTES : 0);
       }
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
