@@ -82,8 +82,10 @@ int spgemm_device_count(int *count);
 int spgemm_create(int device, spgemm_ctx **ctx);
 int spgemm_destroy(spgemm_ctx *ctx);
 int spgemm_ctx_device(const spgemm_ctx *ctx, int *device);
-/* Run on a caller-owned hipStream_t (e.g. the framework's current stream). NULL restores the
- * context's own stream. */
+/* Run on a caller-owned hipStream_t (e.g. the framework's current stream).  NULL restores the
+ * context's own stream, which is created non-blocking: it does NOT order with work queued on the
+ * device's default (null) stream.  A caller whose producer runs on the default stream passes
+ * hipStreamLegacy, not NULL. */
 int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
 int spgemm_synchronize(spgemm_ctx *ctx);
 /* Tunables, by name (e.g. "window_max_span", "lanes_scale"); unknown names are an error. */

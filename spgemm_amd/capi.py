@@ -231,8 +231,17 @@ class Context:
     def set_option(self, name: str, value: int):
         _check(load().spgemm_set_option(self.handle, name.encode(), int(value)))
 
-    def set_stream(self, hip_stream: int):
-        _check(load().spgemm_set_stream(self.handle, ctypes.c_void_p(hip_stream)))
+    def set_stream(self, hip_stream: Optional[int]):
+        """Run on the caller's hipStream_t, given as an integer handle (torch:
+        `torch.cuda.current_stream().cuda_stream`).  Handle 0 is the device's default stream: it is
+        passed on as hipStreamLegacy (1), because a NULL stream means "the context's own stream" to
+        the library, and that one is created non-blocking and would not order with work queued on
+        the default stream.  `None` restores the context's own stream."""
+        if hip_stream is None:
+            h = None
+        else:
+            h = int(hip_stream) or 1
+        _check(load().spgemm_set_stream(self.handle, ctypes.c_void_p(h)))
 
     def synchronize(self):
         _check(load().spgemm_synchronize(self.handle))

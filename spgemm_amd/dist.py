@@ -107,6 +107,28 @@ def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partition
 
 # ---- the exchange (torch tensors, any device) -----------------------------------------------------------
 
+def _staged(device, group=None) -> bool:
+    """True when the collectives must go through host memory: the process group is gloo (which
+    has no device all-to-all) while the data lives on a GPU.  This is the rehearsal mode that runs
+    several ranks on one GPU; with the "nccl" backend (RCCL) nothing is staged."""
+    import torch
+    import torch.distributed as dist
+    return torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, op=None, group=None):
+    """all_reduce of a small tensor on whatever device the backend can reach; returns the result
+    on t's device."""
+    import torch.distributed as dist
+    kw = {} if op is None else {"op": op}
+    if _staged(t.device, group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group, **kw)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group, **kw)
+    return t
+
+
 class SectionExchange:
     """All-to-all of B row sections.  Holds this rank's B block as torch tensors and, from the
     gathered bitmaps and the global per-section entry counts, the split sizes of the collective.
@@ -132,8 +154,8 @@ class SectionExchange:
         sec_nnz = np.zeros(n_sections, dtype=np.int64)
         loc = self.sb[my_lo:my_hi + 1] - ops.first_row
         sec_nnz[my_lo:my_hi] = rp[loc[1:]] - rp[loc[:-1]]
-        t = torch.from_numpy(sec_nnz).to(device)
-        dist.all_reduce(t, group=group)
+        self.staged = _staged(device, group)
+        t = _all_reduce(torch.from_numpy(sec_nnz).to(device), group=group)
         self.sec_nnz = t.cpu().numpy()
         self.sec_rows = np.diff(self.sb)
         self.local_nnz_start = rp[loc[:-1]]                       # start of my sections in my arrays
@@ -189,12 +211,17 @@ class SectionExchange:
         send_len = self._pack(self.row_len, 0)
         send_col = self._pack(self.col, 1)
         send_val = self._pack(self.val, 1)
-        recv_len = torch.empty(sum(self.recv_rows), dtype=torch.int32, device=self.device)
-        recv_col = torch.empty(sum(self.recv_nnz), dtype=torch.int32, device=self.device)
-        recv_val = torch.empty(sum(self.recv_nnz), dtype=torch.float64, device=self.device)
+        cdev = "cpu" if self.staged else self.device
+        if self.staged:
+            send_len, send_col, send_val = send_len.cpu(), send_col.cpu(), send_val.cpu()
+        recv_len = torch.empty(sum(self.recv_rows), dtype=torch.int32, device=cdev)
+        recv_col = torch.empty(sum(self.recv_nnz), dtype=torch.int32, device=cdev)
+        recv_val = torch.empty(sum(self.recv_nnz), dtype=torch.float64, device=cdev)
         dist.all_to_all_single(recv_len, send_len, self.recv_rows, self.send_rows, group=self.group)
         dist.all_to_all_single(recv_col, send_col, self.recv_nnz, self.send_nnz, group=self.group)
         dist.all_to_all_single(recv_val, send_val, self.recv_nnz, self.send_nnz, group=self.group)
+        if self.staged:
+            recv_len, recv_col, recv_val = (x.to(self.device) for x in (recv_len, recv_col, recv_val))
         # full-height row pointer: absent rows are empty
         full_len = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
         full_len[self.present_idx + 1] = recv_len.to(torch.int64)
@@ -207,8 +234,9 @@ def gather_bitmaps(my_bits: np.ndarray, device, group=None) -> np.ndarray:
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    mine = torch.from_numpy(np.asarray(my_bits, dtype=np.uint8)).to(device)
-    out = torch.empty(world * len(my_bits), dtype=torch.uint8, device=device)
+    cdev = "cpu" if _staged(device, group) else device
+    mine = torch.from_numpy(np.asarray(my_bits, dtype=np.uint8)).to(cdev)
+    out = torch.empty(world * len(my_bits), dtype=torch.uint8, device=cdev)
     dist.all_gather_into_tensor(out, mine, group=group)
     return out.cpu().numpy().reshape(world, len(my_bits)).astype(bool)
 
@@ -236,8 +264,11 @@ class DistSpgemm:
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         self.ctx = capi.Context(device_index)
-        # run the kernels on torch's current stream: the exchange's tensors are produced there
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # One stream of this operator's own carries the exchange (the collectives are ordered after
+        # it, their results before what follows on it), the tensor work that turns the received
+        # sections into the local B, and the multiply's kernels.
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx.set_stream(self.stream.cuda_stream)
         self.A_shuffle, self.B_shuffle = make_shuffles(A.rows, B.cols, impl, seed)
         if partition == "naive":
             self.partitions = capi.partition_naive(A.rows, B.cols, self.world)
@@ -259,16 +290,19 @@ class DistSpgemm:
 
     def gemm(self):
         """One timed run: exchange of the needed B sections + the local multiply."""
+        torch = self.torch
         if self.C is not None:
             self.C.free()
             self.C = None
-        row_ptr, col, val = self.exchange.run()
-        n = self.ops.n
-        dB = self.ctx.wrap_device(n, self.ops.n_cols, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(),
-                                  val.data_ptr(), validate=False, keepalive=(row_ptr, col, val))
-        self.C = self.ctx.multiply(self.dA, dB)
-        self.last_stats = self.ctx.stats()
-        dB.free()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            row_ptr, col, val = self.exchange.run()
+            n = self.ops.n
+            dB = self.ctx.wrap_device(n, self.ops.n_cols, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(),
+                                      val.data_ptr(), validate=False, keepalive=(row_ptr, col, val))
+            self.C = self.ctx.multiply(self.dA, dB)   # returns after the stream has drained
+            self.last_stats = self.ctx.stats()
+            dB.free()
         return self.C
 
     def result(self) -> HostCsr:
@@ -305,8 +339,15 @@ def bench_main(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SPGEMM_DIST_BACKEND=gloo with SPGEMM_DIST_DEVICE=0 rehearses several ranks on ONE GPU (collectives
+    # staged through host memory); the measured configuration is always nccl, one GPU per rank.
+    backend = os.environ.get("SPGEMM_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("SPGEMM_DIST_DEVICE", local))
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     A, name = bench_mod.make_workload(args)
     op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local)
     for _ in range(args.warmup):
@@ -324,14 +365,14 @@ def bench_main(args):
     t1 = time.perf_counter()
     st = op.last_stats
     t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = _all_reduce(t, op=dist.ReduceOp.MAX)
     sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.exchange.bytes_sent_per_run,
                          st["bytes_algorithmic"]], dtype=torch.float64, device="cuda")
-    dist.all_reduce(sums)
+    sums = _all_reduce(sums)
     drop = torch.tensor([1.0 - float(np.mean(op.bitmap))], dtype=torch.float64, device="cuda")
-    dist.all_reduce(drop)
+    drop = _all_reduce(drop)
     mult_ms = torch.tensor([st["ms_total"]], dtype=torch.float64, device="cuda")
-    dist.all_reduce(mult_ms, op=dist.ReduceOp.MAX)
+    mult_ms = _all_reduce(mult_ms, op=dist.ReduceOp.MAX)
     if rank == 0:
         ms_per_step = float(t.item()) * 1e3 / args.steps
         nprod, nnz_c, nnz_a, nnz_b_local, sent, b_alg = (float(x) for x in sums.tolist())

@@ -140,3 +140,23 @@ def test_staged_api_with_torch_buffers():
         ctx.numeric(d, d, row_ptr.data_ptr(), col.data_ptr(), val.data_ptr())
     d.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_operator_ranks_share_one_gpu(world):
+    """The whole N > 1 operator path (device bitmap, exchange, HIP multiply per rank, merge) with
+    `world` processes on this one GPU; collectives over gloo, staged through host memory."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_dist_gpu_worker.py")]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.stdout.count("DIST_GPU_OK") == 4, p.stdout[-2000:]
