@@ -166,15 +166,16 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t c, uint32_t log2s) {
 // LDS fp64 accumulate: ds_add_f64 (plain IEEE add of an already rounded product).
 __device__ __forceinline__ void lds_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
-// ---- B row info: {min col, max col, length} of every B row ---------------------------------
-// 8 lanes per row; rows may be unsorted.
+// ---- B row info: {min col, max col, length, 1 if the row's columns are not strictly increasing}
+// of every B row; info[rows].x counts the rows that are not strictly increasing (zero on entry).
+// 8 lanes per row.
 __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
                                                    const uint32_t *__restrict__ b_col,
                                                    uint4 *__restrict__ info) {
   constexpr int G = 8;
   uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   uint32_t lg = threadIdx.x & (G - 1);
-  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0, unsorted = 0;
   uint64_t b0 = 0, b1 = 0;
   if (row < rows) {
     b0 = b_ptr[row];
@@ -182,14 +183,17 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
   }
   for (uint64_t j = b0 + lg; j < b1; j += G) {
     uint32_t c = b_col[j];
+    if (j > b0 && b_col[j - 1] >= c) unsorted = 1;
     mn = min(mn, c);
     mx = max(mx, c);
   }
   mn = group_min<G>(mn);
   mx = group_max<G>(mx);
+  unsorted = group_max<G>(unsorted);
   if (row < rows && lg == 0) {
     uint64_t len = b1 - b0;
-    info[row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, 0u);
+    info[row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
+    if (unsorted) atomicAdd(&info[rows].x, 1u);
   }
 }
 
@@ -1015,6 +1019,100 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- symbolic, big rows: one 1024-thread workgroup per row, bitmap windows in LDS ----------------
+// Needs B rows with strictly increasing columns.  The row's column hull is cut into windows of
+// win_words * 32 columns; for every window the 16 wavefronts take the A entries round robin and OR
+// the columns of their B rows into an LDS bitmap, each B row continuing where the previous window
+// stopped (cursor per A entry: in LDS for rows of up to BIG_CUR entries, else g_cur, one uint32
+// per entry of A).  Then every thread counts and writes out the columns of its own run of words.
+// Bitmap word w lives at LDS index w + w / 32, so that the 64 lanes of a wavefront, each walking
+// its own run of 32 words, fall on different banks.
+// LDS: (win_words + win_words / 32) uint32 | BIG_CUR uint32.
+constexpr uint32_t BIG_THREADS = 1024, BIG_WAVES = 16, BIG_CUR = 1024;
+__host__ __device__ inline uint32_t pad33(uint32_t w) { return w + (w >> 5); }
+
+__global__ void __launch_bounds__(BIG_THREADS)
+    k_sym_big(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t win_words,
+              uint32_t *__restrict__ g_cur) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *s_cur = bits + pad33(win_words);
+  __shared__ uint32_t s_wsum[BIG_WAVES];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const uint32_t row = scalar_view(rows)[blockIdx.x];
+  const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
+  const uint32_t len_a = (uint32_t)(a1 - a0);
+  const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
+  uint32_t *cur = len_a <= BIG_CUR ? s_cur : g_cur + a0;
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  const auto a_col = scalar_view(A.col);
+  const auto b_ptr = scalar_view(B.ptr);
+  const uint32_t wpt = win_words / BIG_THREADS; // words per thread
+  uint32_t carry = 0;
+  for (uint32_t wb = w0; wb <= w1; wb += win_words) {
+    const uint32_t nw = min(win_words, w1 + 1u - wb);
+    const bool first = wb == w0, last = wb + nw > w1;
+    const uint64_t chi = (uint64_t)(wb + nw) << 5;
+    for (uint32_t i = 0; i < wpt; ++i) {
+      const uint32_t w = tid * wpt + i;
+      if (w < nw) bits[pad33(w)] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t idx = wv; idx < len_a; idx += BIG_WAVES) {
+      const uint32_t k = a_col[a0 + idx];
+      const uint64_t b0 = b_ptr[k], b1 = b_ptr[k + 1];
+      uint64_t p = b0 + (first ? 0u : cur[idx]);
+      while (p < b1) {
+        const bool have = p + lane < b1;
+        const uint32_t c = have ? B.col[p + lane] : EMPTY_KEY;
+        const bool in = have && (last || (uint64_t)c < chi);
+        if (in) atomicOr(&bits[pad33((c >> 5) - wb)], 1u << (c & 31u));
+        const uint32_t n = (uint32_t)__popcll(__ballot(in));
+        p += n;
+        if (n < 64u) break;
+      }
+      if (!last && lane == 0) cur[idx] = (uint32_t)(p - b0);
+    }
+    __syncthreads();
+    // count, scan over the workgroup, write out
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < wpt; ++i) {
+      const uint32_t w = tid * wpt + i;
+      if (w < nw) cnt += __popc(bits[pad33(w)]);
+    }
+    const uint32_t incl = group_incl_scan<64>(cnt);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BIG_WAVES; ++i) {
+      const uint32_t v = s_wsum[i];
+      base += i < wv ? v : 0u;
+      tot += v;
+    }
+    uint32_t pos = carry + base + incl - cnt;
+    if (cnt) {
+      for (uint32_t i = 0; i < wpt; ++i) {
+        const uint32_t w = tid * wpt + i;
+        if (w >= nw) break;
+        uint32_t b = bits[pad33(w)];
+        const uint32_t cbase = (wb + w) << 5;
+        while (b) {
+          out[pos++] = cbase + (uint32_t)__ffs(b) - 1u;
+          b &= b - 1u;
+        }
+      }
+    }
+    carry += tot;
+    __syncthreads(); // s_wsum and the bitmap are reused by the next window
+  }
+  if (tid == 0) {
+    m.nnz[row] = carry;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry);
+  }
+}
+
 // ---- numeric -----------------------------------------------------------------------------------
 struct NumOut {
   const uint64_t *__restrict__ c_ptr;
@@ -1250,6 +1348,246 @@ __global__ void __launch_bounds__(256)
     double v = vals[p];
     o.c_val[off + p] = v;
     nz += (v == 0.0) ? 1u : 0u;
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// ---- numeric, big rows: slices of the output row, one wavefront per slice ---------------------------
+// Needs B rows with strictly increasing columns.  The sorted structural columns of a big row are
+// cut into chunks of SLICE_W outputs; a work item is a run of consecutive chunks of one row and is
+// carried out by ONE wavefront, chunk after chunk.  For a chunk the wavefront keeps the chunk's
+// columns and accumulators in LDS and walks the A row in storage order, taking from every B row
+// only the entries whose columns fall into the chunk (a contiguous piece, since the B row is
+// sorted): every output still receives its additions in the order of the CPU loop, and different
+// chunks of a row run on different wavefronts at the same time.
+//
+// An item first builds the list of A entries whose B rows reach into its column range at all
+// ({position in B, end position, A value, next column}, in A order; global scratch, `list_cap`
+// entries per workgroup).  A chunk then looks only at the list's `next column` to find the entries
+// it has to touch, and advances their positions for the chunk that follows.
+constexpr uint32_t SLICE_W = 1024;
+constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES; // cols u32 | vals f64 | owner u32 | flat-walk scratch
+
+struct SliceItem {
+  uint32_t row, c0, nc; // chunks [c0, c0 + nc) of the row
+};
+
+// chunks per item: long A rows get longer runs, so that building the list pays off
+__host__ __device__ inline uint32_t slice_run(uint32_t len_a) {
+  uint32_t g = len_a / 64u;
+  return g < 1u ? 1u : g > 64u ? 64u : g;
+}
+
+__global__ void __launch_bounds__(256)
+    k_slice_count(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
+                  const uint32_t *__restrict__ nnz, uint32_t *__restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const uint32_t row = rows[i];
+  const uint32_t chunks = (nnz[row] + SLICE_W - 1u) / SLICE_W;
+  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]));
+  count[i] = (chunks + g - 1u) / g;
+}
+
+__global__ void __launch_bounds__(256)
+    k_slice_fill(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
+                 const uint32_t *__restrict__ nnz, const uint64_t *__restrict__ offset,
+                 SliceItem *__restrict__ items) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const uint32_t row = rows[i];
+  const uint32_t chunks = (nnz[row] + SLICE_W - 1u) / SLICE_W;
+  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]));
+  uint64_t o = offset[i];
+  for (uint32_t c = 0; c < chunks; c += g) items[o++] = SliceItem{row, c, min(g, chunks - c)};
+}
+
+// longest A row among the rows of the numeric phase's big-row bin (atomic max into out[0], zero on entry)
+__global__ void __launch_bounds__(256)
+    k_slice_maxlen(uint32_t nrows, const uint64_t *__restrict__ a_ptr, const uint8_t *__restrict__ num_key,
+                   uint32_t *__restrict__ out) {
+  uint32_t mx = 0;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x)
+    if (num_key[r] == (uint8_t)NUM_GLOBAL) mx = max(mx, (uint32_t)min((uint64_t)0xFFFFFFFFu, a_ptr[r + 1] - a_ptr[r]));
+  mx = group_max<64>(mx);
+  if ((threadIdx.x & 63u) == 0 && mx) atomicMax(out, mx);
+}
+
+// first position in [lo, hi) of B.col whose column is >= key (per lane)
+__device__ __forceinline__ uint64_t lower_bound_col(const uint32_t *__restrict__ col, uint64_t lo, uint64_t hi,
+                                                    uint64_t key) {
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if ((uint64_t)col[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// `work`: [0] = next item to hand out (zero on entry), total = n_items[0].
+__global__ void __launch_bounds__(64)
+    k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
+                NumOut o, unsigned long long *__restrict__ work, unsigned char *__restrict__ list_scratch,
+                uint64_t list_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t *scol = reinterpret_cast<uint32_t *>(smem);
+  double *vals = reinterpret_cast<double *>(smem + SLICE_W * 4u);
+  uint32_t *owner = reinterpret_cast<uint32_t *>(smem + SLICE_W * 12u);
+  unsigned char *flat = smem + SLICE_W * 16u;
+  uint32_t *st = reinterpret_cast<uint32_t *>(flat);
+  uint64_t *p0s = reinterpret_cast<uint64_t *>(flat + 256);
+  double *avs = reinterpret_cast<double *>(flat + 768);
+  const uint32_t lane = threadIdx.x;
+  // the list of this workgroup: four arrays of list_cap entries
+  uint64_t *l_cur = reinterpret_cast<uint64_t *>(list_scratch + (size_t)blockIdx.x * list_cap * 28u);
+  uint64_t *l_end = l_cur + list_cap;
+  double *l_av = reinterpret_cast<double *>(l_end + list_cap);
+  uint32_t *l_next = reinterpret_cast<uint32_t *>(l_av + list_cap);
+  const uint64_t total_items = n_items[0];
+  for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
+  uint32_t stamp = 0;
+  uint32_t nz = 0;
+  for (;;) {
+    unsigned long long t = 0;
+    if (lane == 0) t = atomicAdd(work, 1ull);
+    t = readlane64(t, 0);
+    if (t >= total_items) break;
+    const SliceItem it = items[t];
+    const uint32_t row = it.row;
+    const uint32_t n = m.nnz[row];
+    const uint64_t off = o.c_ptr[row];
+    const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
+    const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+    const uint32_t chunks = (n + SLICE_W - 1u) / SLICE_W;
+    const bool item_first = it.c0 == 0, item_last = it.c0 + it.nc == chunks;
+    const uint64_t clo_item = item_first ? 0ull : (uint64_t)tin[(size_t)it.c0 * SLICE_W];
+    const uint64_t chi_item = item_last ? (1ull << 32) : (uint64_t)tin[(size_t)(it.c0 + it.nc) * SLICE_W];
+    // -- the list: A entries whose B rows have entries in [clo_item, chi_item)
+    const bool in_regs = a1 - a0 <= 64;
+    uint64_t cur = 0, end = 0;
+    double av = 0.0;
+    uint32_t nextc = EMPTY_KEY;
+    uint32_t nlist = 0;
+    for (uint64_t ab = a0; ab < a1; ab += 64) {
+      const uint64_t ka = ab + lane;
+      uint64_t lo = 0, hi = 0;
+      double a = 0.0;
+      if (ka < a1) {
+        const uint32_t k = A.col[ka];
+        a = A.val[ka];
+        const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+        lo = item_first ? b0 : lower_bound_col(B.col, b0, b1, clo_item);
+        hi = item_last ? b1 : lower_bound_col(B.col, lo, b1, chi_item);
+      }
+      const bool ne = lo < hi;
+      const uint32_t nc0 = ne ? B.col[lo] : EMPTY_KEY;
+      if (in_regs) {
+        cur = lo; end = hi; av = a; nextc = nc0;
+        nlist = 64;
+      } else {
+        const uint64_t mask = __ballot(ne);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (ne) {
+          const uint32_t e = nlist + rank;
+          l_cur[e] = lo; l_end[e] = hi; l_av[e] = a; l_next[e] = nc0;
+        }
+        nlist += (uint32_t)__popcll(mask);
+      }
+    }
+    // -- the chunks
+    for (uint32_t c = it.c0; c < it.c0 + it.nc; ++c) {
+      const uint32_t pbase = c * SLICE_W;
+      const uint32_t ncols = min(SLICE_W, n - pbase);
+      const bool chunk_last = c + 1 == it.c0 + it.nc;   // of the item: takes all that is left of the list
+      const uint64_t chi = chunk_last ? chi_item : (uint64_t)tin[(size_t)pbase + SLICE_W];
+      lds_fence();
+      for (uint32_t p = lane; p < SLICE_W; p += 64) {
+        scol[p] = p < ncols ? tin[(size_t)pbase + p] : EMPTY_KEY;
+        vals[p] = 0.0;
+      }
+      if (stamp > (1u << 25)) { // claims compare tags: start over before the stamp field overflows
+        for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
+        stamp = 0;
+      }
+      lds_fence();
+      auto find = [&](uint32_t col) { // position of a column that is in the chunk
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t s = SLICE_W / 2; s > 0; s >>= 1)
+          if (scol[pos + s] <= col) pos += s;
+        return pos;
+      };
+      for (uint32_t lb = 0; lb < nlist; lb += 64) {
+        const uint32_t e = lb + lane;
+        if (!in_regs) {
+          const bool have = e < nlist;
+          cur = have ? l_cur[e] : 0; end = have ? l_end[e] : 0;
+          nextc = have ? l_next[e] : EMPTY_KEY;
+        }
+        const bool act = cur < end && (uint64_t)nextc < chi;
+        if (!__any(act)) continue;
+        if (!in_regs) av = act ? l_av[e] : 0.0;
+        uint32_t cnt = 0;
+        if (act) {
+          if (chunk_last) {
+            cnt = (uint32_t)(end - cur);
+          } else { // the B row's entries are distinct columns of this chunk: at most ncols, at most chi - nextc
+            uint64_t hi = min(end, cur + min((uint64_t)ncols, chi - nextc));
+            cnt = (uint32_t)(lower_bound_col(B.col, cur + 1, hi, chi) - cur);
+          }
+        }
+        const uint32_t incl = group_incl_scan<64>(cnt);
+        const uint32_t total = group_last<64>(incl);
+        const uint32_t nact = (uint32_t)__popcll(__ballot(act));
+        if (total >= 24u * nact) {
+          // long pieces: one B row at a time, its entries over the lanes (distinct columns: no conflicts)
+          uint64_t mask = __ballot(act);
+          while (mask) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const uint64_t p0 = readlane64(cur, l);
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)l);
+            const double a = readlane_f64(av, l);
+            for (uint32_t j = lane; j < len; j += 64) {
+              const uint32_t col = B.col[p0 + j];
+              const double bv = B.val[p0 + j];
+              lds_add_f64(&vals[find(col)], __dmul_rn(a, bv));
+            }
+          }
+        } else {
+          // short pieces: products laid end to end over the lanes, conflicts resolved in lane order
+          lds_fence();
+          st[lane] = incl - cnt;
+          p0s[lane] = cur;
+          avs[lane] = av;
+          lds_fence();
+          for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool valid = q < total;
+            const uint32_t qq = valid ? q : 0u;
+            uint32_t tt = 0;
+#pragma unroll
+            for (uint32_t sft = 32; sft > 0; sft >>= 1)
+              if (st[tt + sft] <= qq) tt += sft;
+            const uint64_t p = p0s[tt] + (qq - st[tt]);
+            const uint32_t col = valid ? B.col[p] : EMPTY_KEY;
+            const double bv = valid ? B.val[p] : 0.0;
+            const uint32_t pos = valid ? find(col) : 0u;
+            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[tt], bv));
+          }
+        }
+        cur += cnt;
+        nextc = cur < end ? B.col[cur] : EMPTY_KEY;
+        if (!in_regs && act) { l_cur[e] = cur; l_next[e] = nextc; }
+      }
+      lds_fence();
+      for (uint32_t p = lane; p < ncols; p += 64) {
+        const double v = vals[p];
+        o.c_col[off + pbase + p] = scol[p];
+        o.c_val[off + pbase + p] = v;
+        nz += (v == 0.0) ? 1u : 0u;
+      }
+    }
   }
   nz = group_sum<64>(nz);
   if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);

@@ -82,6 +82,12 @@ struct spgemm_ctx {
   Growable temp_cols; // sorted structural columns (symbolic -> numeric)
   Growable gscratch;  // bitmap scratch of the global path (kept zero between uses)
   size_t gscratch_zeroed = 0;
+  Growable big_cur;   // big-row symbolic: one cursor per A entry (rows longer than BIG_CUR)
+  Growable slice_buf; // big-row numeric: item counts, offsets, items, per-workgroup lists
+  uint32_t big_rows = 1;         // big rows of a sorted B: LDS bitmap windows / output slices
+  uint32_t slice_blocks = 0;     // workgroups of the slice kernel (0: fill the device)
+  uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
+  int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
@@ -113,6 +119,7 @@ struct spgemm_ctx {
     unsigned long long *zero_count = nullptr;
     uint32_t pblocks = 0;
     uint64_t nnz_structural = 0;
+    bool b_sorted = false; // every B row has strictly increasing columns
   } plan;
   size_t arena_used = 0;
 };
@@ -233,7 +240,8 @@ static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uin
 static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   if (B->d_rowinfo) return SPGEMM_OK;
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
-  TRY(pool_alloc(ctx, std::max<uint64_t>(B->rows, 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
+  TRY(pool_alloc(ctx, (B->rows + 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
+  HIP_TRY(hipMemsetAsync(mb->d_rowinfo + B->rows, 0, sizeof(uint4), ctx->stream)); // count of unsorted rows
   if (B->rows) {
     uint32_t blocks = div_up_u64(B->rows * 8, 256);
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
@@ -244,19 +252,21 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
 }
 
 // ---- LDS limits ------------------------------------------------------------------------------------
-static bool g_attr_set = false;
 template <class K> static void raise_lds_limit(K kernel) {
+  hipFuncAttributes fa;
+  size_t fixed = 0; // LDS the kernel declares statically counts against the same 160 KiB
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel)) == hipSuccess) fixed = fa.sharedSizeBytes;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+                            (int)(160 * 1024 - fixed));
+  (void)hipGetLastError(); // a refusal shows again, with the kernel's name, at the launch that needs the room
 }
-static void raise_all_lds_limits() {
-  if (g_attr_set) return;
+static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
   raise_lds_limit(k_num_window_grp);
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
-  g_attr_set = true;
+  raise_lds_limit(k_sym_big);
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -317,6 +327,11 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
     return fail(SPGEMM_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
   }
   raise_all_lds_limits();
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      ctx->cu_count = cus;
+  }
   *out = ctx;
   return SPGEMM_OK;
 }
@@ -330,6 +345,8 @@ extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   if (ctx->arena.p) (void)hipFree(ctx->arena.p);
   if (ctx->temp_cols.p) (void)hipFree(ctx->temp_cols.p);
   if (ctx->gscratch.p) (void)hipFree(ctx->gscratch.p);
+  if (ctx->big_cur.p) (void)hipFree(ctx->big_cur.p);
+  if (ctx->slice_buf.p) (void)hipFree(ctx->slice_buf.p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->d_small) (void)hipFree(ctx->d_small);
   for (auto &ev : ctx->ev)
@@ -393,6 +410,15 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "global_blocks_sym") {
     if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "global_blocks_sym must be 1..4096");
     ctx->global_blocks_sym = (uint32_t)value;
+  } else if (n == "big_rows") {
+    ctx->big_rows = value != 0;
+  } else if (n == "big_win_words") {
+    if (value < (int64_t)BIG_THREADS || value > 32768 || value % BIG_THREADS)
+      return fail(SPGEMM_ERR_INVALID, "big_win_words must be a multiple of 1024 in 1024..32768");
+    ctx->big_win_words = (uint32_t)value;
+  } else if (n == "slice_blocks") {
+    if (value < 0 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_blocks must be 0..65536");
+    ctx->slice_blocks = (uint32_t)value;
   } else if (n == "global_blocks_num") {
     if (value < 1 || value > 16384) return fail(SPGEMM_ERR_INVALID, "global_blocks_num must be 1..16384");
     ctx->global_blocks_num = (uint32_t)value;
@@ -577,6 +603,8 @@ struct HostCounts {
   uint64_t total_a; // total_ub (symbolic phase) or nnz (numeric phase)
   uint64_t total_nprod;
   uint32_t long_count;
+  uint32_t b_unsorted;  // B rows whose columns are not strictly increasing
+  uint32_t max_len_big; // longest A row among the numeric phase's big rows
   uint32_t pad;
   uint64_t nprod_parts[NPROD_SLOTS];
 };
@@ -666,7 +694,9 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (SYM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(hc->nprod_parts, total_nprod, NPROD_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->b_unsorted, &B->d_rowinfo[B->rows].x, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const bool b_sorted = hc->b_unsorted == 0;
   st.nprod = 0;
   for (uint32_t i = 0; i < NPROD_SLOTS; ++i) st.nprod += hc->nprod_parts[i];
   const uint64_t total_ub = hc->total_a;
@@ -703,6 +733,15 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       TRY(prof_begin(ctx, 0, 1, flat ? 0 : 64, cnt, log2s, 0, region * wpb, rows_bin));
       hipLaunchKernelGGL(flat ? k_sym_hash<true> : k_sym_hash<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
+    } else if (b_sorted && ctx->big_rows) {
+      // windows of up to 2^20 columns (128 KiB of LDS); a narrower matrix gets one window
+      uint32_t win_words = (uint32_t)std::min<uint64_t>(ctx->big_win_words, align_up((B->cols + 31) / 32, BIG_THREADS));
+      size_t lds = ((size_t)pad33(win_words) + BIG_CUR) * 4;
+      if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 4));
+      st.rows_global += cnt;
+      TRY(prof_begin(ctx, 0, 2, 64, cnt, win_words, 0, lds, rows_bin));
+      hipLaunchKernelGGL(k_sym_big, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, win_words,
+                         reinterpret_cast<uint32_t *>(ctx->big_cur.p));
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
@@ -731,6 +770,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.r_gcnt = r_gcnt; pl.r_lead = r_lead;
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
+  pl.b_sorted = b_sorted;
   pl.valid = true;
   return SPGEMM_OK;
 }
@@ -755,8 +795,18 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, perm, bin_off));
   HIP_TRY(hipMemsetAsync(zero_count, 0, 256, ctx->stream));
   HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
+  // zero_count[1]: work counter of the slice kernel; zero_count[2] (low word): longest big A row
+  uint32_t *max_len_big = reinterpret_cast<uint32_t *>(zero_count + 2);
+  const bool slices = pl.b_sorted && ctx->big_rows;
+  if (slices) {
+    hipLaunchKernelGGL(k_slice_maxlen, dim3(std::min<uint32_t>(div_up_u64(rows, 256), 2048)), dim3(256), 0, ctx->stream,
+                       rows, A->d_ptr, pl.r_numkey, max_len_big);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&hc->max_len_big, max_len_big, 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (NUM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint64_t list_cap = slices ? std::max<uint32_t>(hc->max_len_big, 64) : 0;
   uint64_t boff[NUM_NBINS + 1];
   memcpy(boff, hc->bin_off, sizeof(boff));
   HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -807,6 +857,28 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       else
         hipLaunchKernelGGL(flat ? k_num_hash<true> : k_num_hash<false>, grid, block, lds, ctx->stream, rows_bin, cnt, cA,
                            cB, rm, no, p0, wpb);
+    } else if (slices) {
+      // items = runs of chunks of SLICE_W outputs; at most one per chunk
+      const uint64_t max_items = nnz_structural / SLICE_W + cnt;
+      uint32_t blocks = ctx->slice_blocks ? ctx->slice_blocks : (uint32_t)ctx->cu_count * (uint32_t)(lds_max / SLICE_LDS);
+      blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)4 << 30) / (list_cap * 28)));
+      const size_t b_count = align_up((size_t)cnt * 4, 256), b_off = align_up(((size_t)cnt + 1) * 8, 256);
+      const size_t b_items = align_up(max_items * sizeof(SliceItem), 256);
+      const size_t b_lists = (size_t)blocks * list_cap * 28;
+      TRY(grow(ctx, ctx->slice_buf, b_count + b_off + b_items + b_lists));
+      char *sb = reinterpret_cast<char *>(ctx->slice_buf.p);
+      uint32_t *s_count = reinterpret_cast<uint32_t *>(sb);
+      uint64_t *s_off = reinterpret_cast<uint64_t *>(sb + b_count);
+      SliceItem *s_items = reinterpret_cast<SliceItem *>(sb + b_count + b_off);
+      unsigned char *s_lists = reinterpret_cast<unsigned char *>(sb + b_count + b_off + b_items);
+      TRY(prof_begin(ctx, 1, 2, 64, cnt, SLICE_W, blocks, SLICE_LDS, rows_bin));
+      hipLaunchKernelGGL(k_slice_count, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
+                         pl.r_nnz, s_count);
+      TRY(launch_scan(ctx, s_count, cnt, s_off, partial));
+      hipLaunchKernelGGL(k_slice_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
+                         pl.r_nnz, s_off, s_items);
+      hipLaunchKernelGGL(k_num_slice, dim3(blocks), dim3(64), SLICE_LDS, ctx->stream, s_items, s_off + cnt, cA, cB, rm, no,
+                         zero_count + 1, s_lists, list_cap);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
@@ -885,7 +957,7 @@ static int finish_stats(spgemm_ctx *ctx, uint64_t rows_c, uint64_t nnz_final) {
   }
   st.nnz_c = nnz_final;
   st.bytes_algorithmic = 12ull * (st.nnz_a + st.nprod + st.nnz_c) + 4ull * (st.rows_a + 1) + 8ull * (rows_c + 1);
-  st.temp_bytes = ctx->arena.cap + ctx->temp_cols.cap + ctx->gscratch.cap;
+  st.temp_bytes = ctx->arena.cap + ctx->temp_cols.cap + ctx->gscratch.cap + ctx->big_cur.cap + ctx->slice_buf.cap;
   return SPGEMM_OK;
 }
 

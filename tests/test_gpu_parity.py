@@ -225,3 +225,67 @@ def test_row_groups_with_cancellation_and_order(ctx):
     B = hostcsr.HostCsr.from_coo(n, n, Br, Bc, Bv)
     C, st = check(ctx, A, B)
     assert st["nnz_structural"] >= C.nnz
+
+
+def _big_row_matrix(seed):
+    """R-MAT plus a few dense-ish hub rows: output rows of several thousand entries, A rows longer
+    than one wavefront and than the in-LDS cursor table."""
+    A = hostcsr.rmat(13, 8, seed=seed)
+    rng = np.random.default_rng(seed)
+    n = A.rows
+    r, c, v = [A.row_ids()], [A.col_idx.astype(np.int64)], [A.val]
+    for hub, ln in ((5, 3000), (77, 1500), (n - 3, 200), (n // 2, 70)):
+        cols = rng.choice(n, size=ln, replace=False)
+        r.append(np.full(ln, hub)); c.append(cols); v.append(rng.uniform(-1, 1, ln))
+    return hostcsr.HostCsr.from_coo(n, n, np.concatenate(r), np.concatenate(c), np.concatenate(v),
+                                   sum_duplicates=True).sorted_rows()
+
+
+@pytest.mark.parametrize("win_words", [32768, 1024])
+def test_big_rows_slices_and_windows(ctx, win_words):
+    """Big-row kernels: several bitmap windows per row (small window forced), output rows cut into
+    many slices, long A rows (list in global scratch, runs of several chunks per item)."""
+    A = _big_row_matrix(9)
+    ctx.set_option("window_max_span", 0)
+    ctx.set_option("hash_max_nprod", 64)
+    ctx.set_option("big_win_words", win_words)
+    try:
+        _, st = check(ctx, A, A)
+        assert st["rows_global"] > 1000
+    finally:
+        ctx.set_option("window_max_span", 65536)
+        ctx.set_option("hash_max_nprod", 4096)
+        ctx.set_option("big_win_words", 32768)
+
+
+def test_big_rows_few_workgroups(ctx):
+    """The slice kernel hands out items through a counter: one workgroup must drain them all."""
+    A = _big_row_matrix(10)
+    ctx.set_option("window_max_span", 0)
+    ctx.set_option("slice_blocks", 1)
+    try:
+        check(ctx, A, A)
+        ctx.set_option("slice_blocks", 3)
+        check(ctx, A, A)
+    finally:
+        ctx.set_option("window_max_span", 65536)
+        ctx.set_option("slice_blocks", 0)
+
+
+def test_unsorted_b_rows_take_the_general_path(ctx):
+    """B rows that are not sorted by column: the big-row kernels (which rely on sorted B rows) are
+    not used, the result is the same."""
+    A = hostcsr.rmat(11, 8, seed=5)
+    rng = np.random.default_rng(0)
+    col, val = A.col_idx.copy(), A.val.copy()
+    rp = A.row_ptr.astype(np.int64)
+    for r in range(A.rows):  # random order inside every row
+        p = rng.permutation(rp[r + 1] - rp[r]) + rp[r]
+        col[rp[r]:rp[r + 1]] = A.col_idx[p]
+        val[rp[r]:rp[r + 1]] = A.val[p]
+    Bu = hostcsr.HostCsr(A.rows, A.cols, A.row_ptr, col, val)
+    ctx.set_option("window_max_span", 0)
+    try:
+        check(ctx, A, Bu)
+    finally:
+        ctx.set_option("window_max_span", 65536)
