@@ -1021,67 +1021,168 @@ __global__ void __launch_bounds__(256)
 
 // ---- symbolic, big rows: one 1024-thread workgroup per row, bitmap windows in LDS ----------------
 // Needs B rows with strictly increasing columns.  The row's column hull is cut into windows of
-// win_words * 32 columns; for every window the 16 wavefronts take the A entries round robin and OR
-// the columns of their B rows into an LDS bitmap, each B row continuing where the previous window
-// stopped (cursor per A entry: in LDS for rows of up to BIG_CUR entries, else g_cur, one uint32
-// per entry of A).  Then every thread counts and writes out the columns of its own run of words.
-// Bitmap word w lives at LDS index w + w / 32, so that the 64 lanes of a wavefront, each walking
-// its own run of 32 words, fall on different banks.
-// LDS: (win_words + win_words / 32) uint32 | BIG_CUR uint32.
-constexpr uint32_t BIG_THREADS = 1024, BIG_WAVES = 16, BIG_CUR = 1024;
-__host__ __device__ inline uint32_t pad33(uint32_t w) { return w + (w >> 5); }
+// win_words * 32 columns.  Every A entry keeps {position, end} of what is left of its B row (in
+// LDS for rows of up to BIG_CUR entries, else in g_state, two uint64 per entry of A); in a window
+// the part of the B row that falls into it (a "piece": contiguous, the B row is sorted) is ORed
+// into the LDS bitmap and the position moves on.  Pieces are classified by what is left of the B
+// row: up to BIG_MID entries -> one wavefront takes the piece, four pieces at a time, all their
+// loads in flight together; more -> all 16 wavefronts take 1024 entries of the piece per step,
+// four pieces at a time, and a wavefront stops at its first block that leaves the window.
+// The bitmap is then written out in blocks of 256 words (four per lane, the blocks dealt to the
+// wavefronts round robin): block totals, a scan over the blocks, and every lane writes the
+// columns of its own four words, at most 128.
+// LDS: win_words u32 bitmap | BIG_CUR u64 pos | BIG_CUR u64 end | BIG_CUR u32 list of mid pieces |
+//      BIG_CUR u32 list of long pieces | BIG_CUR u32 entries taken from long pieces | win_words / 64 u32 (block offsets; a quarter used).
+constexpr uint32_t BIG_THREADS = 1024, BIG_WAVES = 16, BIG_CUR = 1024, BIG_MID = 256;
+constexpr uint32_t BIG_WIN_MAX = 32768;                   // words of the largest window
+constexpr uint32_t BIG_BPW = BIG_WIN_MAX / 256 / BIG_WAVES; // blocks of 256 words per wavefront and window
+__host__ __device__ inline size_t sym_big_lds(uint32_t win_words) {
+  return (size_t)win_words * 4 + (size_t)BIG_CUR * (8 + 8 + 4 + 4 + 4) + (size_t)(win_words / 64) * 4;
+}
 
 __global__ void __launch_bounds__(BIG_THREADS)
     k_sym_big(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t win_words,
-              uint32_t *__restrict__ g_cur) {
+              uint64_t *__restrict__ g_state, uint64_t nnz_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
-  uint32_t *s_cur = bits + pad33(win_words);
+  uint64_t *s_pos = reinterpret_cast<uint64_t *>(smem + (size_t)win_words * 4);
+  uint64_t *s_end = s_pos + BIG_CUR;
+  uint32_t *s_mid = reinterpret_cast<uint32_t *>(s_end + BIG_CUR);
+  uint32_t *s_long = s_mid + BIG_CUR;
+  uint32_t *s_cnt = s_long + BIG_CUR;
+  uint32_t *s_blk = s_cnt + BIG_CUR; // per block of 64 words: set bits, then offset of its first column
   __shared__ uint32_t s_wsum[BIG_WAVES];
+  __shared__ uint32_t s_n[2]; // mid pieces, long pieces of the current batch
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const uint32_t row = scalar_view(rows)[blockIdx.x];
   const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
   const uint32_t len_a = (uint32_t)(a1 - a0);
   const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
-  uint32_t *cur = len_a <= BIG_CUR ? s_cur : g_cur + a0;
+  uint64_t *pos = len_a <= BIG_CUR ? s_pos : g_state + a0;
+  uint64_t *end = len_a <= BIG_CUR ? s_end : g_state + nnz_a + a0;
   uint32_t *out = m.temp_cols + m.t_off[row];
-  const auto a_col = scalar_view(A.col);
-  const auto b_ptr = scalar_view(B.ptr);
-  const uint32_t wpt = win_words / BIG_THREADS; // words per thread
   uint32_t carry = 0;
+  if (tid < 2) s_n[tid] = 0u;
   for (uint32_t wb = w0; wb <= w1; wb += win_words) {
     const uint32_t nw = min(win_words, w1 + 1u - wb);
+    const uint32_t nblk = (nw + 255u) >> 8;
     const bool first = wb == w0, last = wb + nw > w1;
     const uint64_t chi = (uint64_t)(wb + nw) << 5;
-    for (uint32_t i = 0; i < wpt; ++i) {
-      const uint32_t w = tid * wpt + i;
-      if (w < nw) bits[pad33(w)] = 0u;
-    }
+    for (uint32_t w = tid * 4u; w < nblk * 256u; w += BIG_THREADS * 4u)
+      *reinterpret_cast<uint4 *>(&bits[w]) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    for (uint32_t idx = wv; idx < len_a; idx += BIG_WAVES) {
-      const uint32_t k = a_col[a0 + idx];
-      const uint64_t b0 = b_ptr[k], b1 = b_ptr[k + 1];
-      uint64_t p = b0 + (first ? 0u : cur[idx]);
-      while (p < b1) {
-        const bool have = p + lane < b1;
-        const uint32_t c = have ? B.col[p + lane] : EMPTY_KEY;
-        const bool in = have && (last || (uint64_t)c < chi);
-        if (in) atomicOr(&bits[pad33((c >> 5) - wb)], 1u << (c & 31u));
-        const uint32_t n = (uint32_t)__popcll(__ballot(in));
-        p += n;
-        if (n < 64u) break;
+    for (uint32_t kb = 0; kb < len_a; kb += BIG_CUR) {
+      // classify what is left of every B row of this batch of A entries
+      const uint32_t idx = kb + tid;
+      if (idx < len_a) {
+        uint64_t p, e;
+        if (first) {
+          const uint32_t k = A.col[a0 + idx];
+          p = B.ptr[k];
+          e = B.ptr[k + 1];
+          pos[idx] = p;
+          end[idx] = e;
+        } else {
+          p = pos[idx];
+          e = end[idx];
+        }
+        const uint64_t rem = e - p;
+        if (rem > BIG_MID) {
+          const uint32_t slot = atomicAdd(&s_n[1], 1u);
+          s_long[slot] = idx;
+          s_cnt[slot] = 0u;
+        } else if (rem) {
+          s_mid[atomicAdd(&s_n[0], 1u)] = idx;
+        }
       }
-      if (!last && lane == 0) cur[idx] = (uint32_t)(p - b0);
+      __syncthreads();
+      const uint32_t nmid = s_n[0], nlong = s_n[1];
+      // mid pieces: a wavefront takes four pieces and all of their (up to 4 x 64) entries at once
+      for (uint32_t e0 = wv * 4u; e0 < nmid; e0 += BIG_WAVES * 4u) {
+        uint32_t id[4], c[4][4];
+        uint64_t p[4];
+        uint32_t rem[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = e0 + u < nmid;
+          id[u] = s_mid[on ? e0 + u : e0];
+          p[u] = pos[id[u]];
+          rem[u] = on ? (uint32_t)(end[id[u]] - p[u]) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[u][j] = (64u * j + lane < rem[u]) ? B.col[p[u] + 64u * j + lane] : EMPTY_KEY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          uint32_t took = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool in = 64u * j + lane < rem[u] && (last || (uint64_t)c[u][j] < chi);
+            if (in) atomicOr(&bits[(c[u][j] >> 5) - wb], 1u << (c[u][j] & 31u));
+            took += (uint32_t)__popcll(__ballot(in));
+          }
+          if (lane == 0 && rem[u]) pos[id[u]] = p[u] + took;
+        }
+      }
+      // long pieces: all wavefronts, 1024 entries of a piece per step, four pieces at a time
+      for (uint32_t e0 = 0; e0 < nlong; e0 += 4u) {
+        uint32_t c[4];
+        uint64_t p[4], rem[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = e0 + u < nlong;
+          const uint32_t id = s_long[on ? e0 + u : e0];
+          p[u] = pos[id];
+          rem[u] = on ? end[id] - p[u] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = tid < rem[u] ? B.col[p[u] + tid] : EMPTY_KEY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool in = tid < rem[u] && (last || (uint64_t)c[u] < chi);
+          if (in) atomicOr(&bits[(c[u] >> 5) - wb], 1u << (c[u] & 31u));
+          uint32_t n = (uint32_t)__popcll(__ballot(in));
+          uint32_t took = n;
+          for (uint64_t base = BIG_THREADS; n == 64u && base + wv * 64u < rem[u]; base += BIG_THREADS) {
+            const uint64_t j = base + tid;
+            const bool have = j < rem[u];
+            const uint32_t c2 = have ? B.col[p[u] + j] : EMPTY_KEY;
+            const bool in2 = have && (last || (uint64_t)c2 < chi);
+            if (in2) atomicOr(&bits[(c2 >> 5) - wb], 1u << (c2 & 31u));
+            n = (uint32_t)__popcll(__ballot(in2));
+            took += n;
+          }
+          if (lane == 0 && took) atomicAdd(&s_cnt[e0 + u], took);
+        }
+      }
+      __syncthreads();
+      if (tid < nlong) pos[s_long[tid]] += s_cnt[tid];
+      if (tid < 2) s_n[tid] = 0u;
+      __syncthreads();
+    }
+    // set bits per block of 256 words (four per lane); the words stay in registers for the write-out
+    uint4 wd[BIG_BPW];
+    uint32_t ex[BIG_BPW];
+#pragma unroll
+    for (uint32_t i = 0; i < BIG_BPW; ++i) {
+      const uint32_t b = wv + BIG_WAVES * i;
+      wd[i] = make_uint4(0u, 0u, 0u, 0u);
+      ex[i] = 0u;
+      if (b < nblk) { // wave-uniform
+        wd[i] = *reinterpret_cast<const uint4 *>(&bits[b * 256u + lane * 4u]);
+        const uint32_t pc = __popc(wd[i].x) + __popc(wd[i].y) + __popc(wd[i].z) + __popc(wd[i].w);
+        uint32_t incl = 0;
+        if (__ballot(pc != 0u)) incl = group_incl_scan<64>(pc);
+        ex[i] = incl - pc;
+        if (lane == 63) s_blk[b] = incl;
+      }
     }
     __syncthreads();
-    // count, scan over the workgroup, write out
-    uint32_t cnt = 0;
-    for (uint32_t i = 0; i < wpt; ++i) {
-      const uint32_t w = tid * wpt + i;
-      if (w < nw) cnt += __popc(bits[pad33(w)]);
-    }
-    const uint32_t incl = group_incl_scan<64>(cnt);
+    // exclusive scan over the blocks (nblk <= 128): one block per thread
+    const uint32_t bc = tid < nblk ? s_blk[tid] : 0u;
+    const uint32_t incl = group_incl_scan<64>(bc);
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -1091,21 +1192,26 @@ __global__ void __launch_bounds__(BIG_THREADS)
       base += i < wv ? v : 0u;
       tot += v;
     }
-    uint32_t pos = carry + base + incl - cnt;
-    if (cnt) {
-      for (uint32_t i = 0; i < wpt; ++i) {
-        const uint32_t w = tid * wpt + i;
-        if (w >= nw) break;
-        uint32_t b = bits[pad33(w)];
-        const uint32_t cbase = (wb + w) << 5;
-        while (b) {
-          out[pos++] = cbase + (uint32_t)__ffs(b) - 1u;
-          b &= b - 1u;
+    if (tid < nblk) s_blk[tid] = carry + base + incl - bc;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < BIG_BPW; ++i) {
+      const uint32_t b = wv + BIG_WAVES * i;
+      if (b >= nblk) break;
+      uint32_t at = s_blk[b] + ex[i];
+      const uint32_t cbase = (wb + b * 256u + lane * 4u) << 5;
+      const uint32_t w4[4] = {wd[i].x, wd[i].y, wd[i].z, wd[i].w};
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        uint32_t word = w4[j];
+        while (word) {
+          out[at++] = cbase + 32u * j + (uint32_t)__ffs(word) - 1u;
+          word &= word - 1u;
         }
       }
     }
     carry += tot;
-    __syncthreads(); // s_wsum and the bitmap are reused by the next window
+    __syncthreads(); // the bitmap, s_blk and s_wsum are reused by the next window
   }
   if (tid == 0) {
     m.nnz[row] = carry;
@@ -1367,7 +1473,7 @@ __global__ void __launch_bounds__(256)
 // entries per workgroup).  A chunk then looks only at the list's `next column` to find the entries
 // it has to touch, and advances their positions for the chunk that follows.
 constexpr uint32_t SLICE_W = 1024;
-constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES; // cols u32 | vals f64 | owner u32 | flat-walk scratch
+constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES + 512u; // cols u32 | vals f64 | owner u32 | flat-walk scratch | ring
 
 struct SliceItem {
   uint32_t row, c0, nc; // chunks [c0, c0 + nc) of the row
@@ -1376,7 +1482,7 @@ struct SliceItem {
 // chunks per item: long A rows get longer runs, so that building the list pays off
 __host__ __device__ inline uint32_t slice_run(uint32_t len_a) {
   uint32_t g = len_a / 64u;
-  return g < 1u ? 1u : g > 64u ? 64u : g;
+  return g < 4u ? 4u : g > 64u ? 64u : g;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1423,12 +1529,39 @@ __device__ __forceinline__ uint64_t lower_bound_col(const uint32_t *__restrict__
   }
   return lo;
 }
+// the same for N independent ranges per lane, their loads in flight together
+template <int N>
+__device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ col, uint64_t (&lo)[N], uint64_t (&hi)[N],
+                                                  uint64_t key) {
+  for (;;) {
+    bool open = false;
+#pragma unroll
+    for (int u = 0; u < N; ++u) open |= lo[u] < hi[u];
+    if (!__any(open)) break;
+    uint32_t c[N];
+    uint64_t mid[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1);
+      c[u] = lo[u] < hi[u] ? col[mid[u]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+      if (lo[u] < hi[u]) {
+        if ((uint64_t)c[u] < key) lo[u] = mid[u] + 1; else hi[u] = mid[u];
+      }
+  }
+}
 
-// `work`: [0] = next item to hand out (zero on entry), total = n_items[0].
+// `work`: [0] = next item to hand out (zero on entry), total = n_items[0].  o.zero_count[3] is set
+// when a list entry read back from scratch is not a position inside B (never seen; it would mean
+// that the list was damaged) - the entry is skipped and the host reports the multiply as failed.
+// list_scratch: per workgroup, list_cap entries of {cur u64 | end u64 | av f64 | next u32 | pad}.
+constexpr uint32_t SLICE_ENTRY_BYTES = 32;
 __global__ void __launch_bounds__(64)
     k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
                 NumOut o, unsigned long long *__restrict__ work, unsigned char *__restrict__ list_scratch,
-                uint64_t list_cap) {
+                uint64_t list_cap, uint64_t nnz_b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *scol = reinterpret_cast<uint32_t *>(smem);
   double *vals = reinterpret_cast<double *>(smem + SLICE_W * 4u);
@@ -1437,9 +1570,9 @@ __global__ void __launch_bounds__(64)
   uint32_t *st = reinterpret_cast<uint32_t *>(flat);
   uint64_t *p0s = reinterpret_cast<uint64_t *>(flat + 256);
   double *avs = reinterpret_cast<double *>(flat + 768);
+  uint32_t *ring = reinterpret_cast<uint32_t *>(flat + FLAT_BYTES); // 128 list indices
   const uint32_t lane = threadIdx.x;
-  // the list of this workgroup: four arrays of list_cap entries
-  uint64_t *l_cur = reinterpret_cast<uint64_t *>(list_scratch + (size_t)blockIdx.x * list_cap * 28u);
+  uint64_t *l_cur = reinterpret_cast<uint64_t *>(list_scratch + (size_t)blockIdx.x * list_cap * SLICE_ENTRY_BYTES);
   uint64_t *l_end = l_cur + list_cap;
   double *l_av = reinterpret_cast<double *>(l_end + list_cap);
   uint32_t *l_next = reinterpret_cast<uint32_t *>(l_av + list_cap);
@@ -1447,6 +1580,7 @@ __global__ void __launch_bounds__(64)
   for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
   uint32_t stamp = 0;
   uint32_t nz = 0;
+  constexpr int U = 4; // B row pieces whose loads and column searches are in flight together
   for (;;) {
     unsigned long long t = 0;
     if (lane == 0) t = atomicAdd(work, 1ull);
@@ -1462,44 +1596,69 @@ __global__ void __launch_bounds__(64)
     const bool item_first = it.c0 == 0, item_last = it.c0 + it.nc == chunks;
     const uint64_t clo_item = item_first ? 0ull : (uint64_t)tin[(size_t)it.c0 * SLICE_W];
     const uint64_t chi_item = item_last ? (1ull << 32) : (uint64_t)tin[(size_t)(it.c0 + it.nc) * SLICE_W];
-    // -- the list: A entries whose B rows have entries in [clo_item, chi_item)
+    // -- the list: A entries whose B rows have entries in [clo_item, chi_item), in A order.  A row of
+    //    up to 64 entries keeps it in registers (one entry per lane).
     const bool in_regs = a1 - a0 <= 64;
     uint64_t cur = 0, end = 0;
     double av = 0.0;
     uint32_t nextc = EMPTY_KEY;
     uint32_t nlist = 0;
-    for (uint64_t ab = a0; ab < a1; ab += 64) {
-      const uint64_t ka = ab + lane;
-      uint64_t lo = 0, hi = 0;
-      double a = 0.0;
+    if (in_regs) {
+      const uint64_t ka = a0 + lane;
+      uint64_t lo = 0, b1 = 0;
       if (ka < a1) {
         const uint32_t k = A.col[ka];
-        a = A.val[ka];
-        const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+        av = A.val[ka];
+        const uint64_t b0 = B.ptr[k];
+        b1 = B.ptr[k + 1];
         lo = item_first ? b0 : lower_bound_col(B.col, b0, b1, clo_item);
-        hi = item_last ? b1 : lower_bound_col(B.col, lo, b1, chi_item);
       }
-      const bool ne = lo < hi;
-      const uint32_t nc0 = ne ? B.col[lo] : EMPTY_KEY;
-      if (in_regs) {
-        cur = lo; end = hi; av = a; nextc = nc0;
-        nlist = 64;
-      } else {
-        const uint64_t mask = __ballot(ne);
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (ne) {
-          const uint32_t e = nlist + rank;
-          l_cur[e] = lo; l_end[e] = hi; l_av[e] = a; l_next[e] = nc0;
+      nextc = lo < b1 ? B.col[lo] : EMPTY_KEY;
+      const bool ne = lo < b1 && (uint64_t)nextc < chi_item;
+      cur = ne ? lo : 0;
+      end = ne ? b1 : 0;
+      if (!ne) nextc = EMPTY_KEY;
+    } else {
+      for (uint64_t ab = a0; ab < a1; ab += 64 * U) { // U blocks of 64 entries, their searches together
+        uint64_t lo[U], hi[U], b1[U];
+        double a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint64_t ka = ab + 64u * u + lane;
+          lo[u] = hi[u] = b1[u] = 0;
+          a[u] = 0.0;
+          if (ka < a1) {
+            const uint32_t k = A.col[ka];
+            a[u] = A.val[ka];
+            lo[u] = B.ptr[k];
+            b1[u] = B.ptr[k + 1];
+            hi[u] = item_first ? lo[u] : b1[u]; // empty range: nothing to search
+          }
         }
-        nlist += (uint32_t)__popcll(mask);
+        lower_bound_col_n<U>(B.col, lo, hi, clo_item);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t nc0 = lo[u] < b1[u] ? B.col[lo[u]] : EMPTY_KEY;
+          const bool ne = lo[u] < b1[u] && (uint64_t)nc0 < chi_item;
+          const uint64_t mask = __ballot(ne);
+          if (ne) {
+            const uint32_t e = nlist + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            l_cur[e] = lo[u]; l_end[e] = b1[u]; l_av[e] = a[u]; l_next[e] = nc0;
+          }
+          nlist += (uint32_t)__popcll(mask);
+        }
       }
+      // the list is read back by other lanes: all its stores have to be done
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     // -- the chunks
     for (uint32_t c = it.c0; c < it.c0 + it.nc; ++c) {
       const uint32_t pbase = c * SLICE_W;
       const uint32_t ncols = min(SLICE_W, n - pbase);
-      const bool chunk_last = c + 1 == it.c0 + it.nc;   // of the item: takes all that is left of the list
+      const bool chunk_last = c + 1 == it.c0 + it.nc; // of the item
       const uint64_t chi = chunk_last ? chi_item : (uint64_t)tin[(size_t)pbase + SLICE_W];
+      const uint32_t chunks_left = chunks - c;
       lds_fence();
       for (uint32_t p = lane; p < SLICE_W; p += 64) {
         scol[p] = p < ncols ? tin[(size_t)pbase + p] : EMPTY_KEY;
@@ -1517,45 +1676,95 @@ __global__ void __launch_bounds__(64)
           if (scol[pos + s] <= col) pos += s;
         return pos;
       };
-      for (uint32_t lb = 0; lb < nlist; lb += 64) {
-        const uint32_t e = lb + lane;
-        if (!in_regs) {
-          const bool have = e < nlist;
-          cur = have ? l_cur[e] : 0; end = have ? l_end[e] : 0;
-          nextc = have ? l_next[e] : EMPTY_KEY;
-        }
-        const bool act = cur < end && (uint64_t)nextc < chi;
-        if (!__any(act)) continue;
-        if (!in_regs) av = act ? l_av[e] : 0.0;
-        uint32_t cnt = 0;
-        if (act) {
-          if (chunk_last) {
-            cnt = (uint32_t)(end - cur);
-          } else { // the B row's entries are distinct columns of this chunk: at most ncols, at most chi - nextc
-            uint64_t hi = min(end, cur + min((uint64_t)ncols, chi - nextc));
-            cnt = (uint32_t)(lower_bound_col(B.col, cur + 1, hi, chi) - cur);
-          }
-        }
-        const uint32_t incl = group_incl_scan<64>(cnt);
-        const uint32_t total = group_last<64>(incl);
-        const uint32_t nact = (uint32_t)__popcll(__ballot(act));
-        if (total >= 24u * nact) {
-          // long pieces: one B row at a time, its entries over the lanes (distinct columns: no conflicts)
-          uint64_t mask = __ballot(act);
+      // One block of up to 64 list entries (one per lane; `act` = has entries in this chunk): adds
+      // their pieces in A order, moves cur / nextc on.
+      auto block = [&](bool act, uint64_t &cur, uint64_t end, double av, uint32_t &nextc) {
+        const uint64_t amask = __ballot(act);
+        const uint32_t nact = (uint32_t)__popcll(amask);
+        // expected length of a piece: what is left of the B row, spread over the chunks that follow
+        const uint32_t est = act ? (uint32_t)min(end - cur, (uint64_t)SLICE_W) / chunks_left : 0u;
+        if (group_sum<64>(est) >= 16u * nact) {
+          // long pieces: one B row at a time, its entries over the lanes (distinct columns: no
+          // conflicts); U pieces are loaded and searched together, then added in A order
+          uint64_t mask = amask;
           while (mask) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const uint64_t p0 = readlane64(cur, l);
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)l);
-            const double a = readlane_f64(av, l);
-            for (uint32_t j = lane; j < len; j += 64) {
-              const uint32_t col = B.col[p0 + j];
-              const double bv = B.val[p0 + j];
-              lds_add_f64(&vals[find(col)], __dmul_rn(a, bv));
+            uint32_t l[U], rem[U], col[U], pos[U];
+            uint64_t p0[U], pend[U];
+            double a[U], v[U];
+            bool on[U], in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              on[u] = mask != 0;
+              l[u] = on[u] ? (uint32_t)__builtin_ctzll(mask) : 0u;
+              if (on[u]) mask &= mask - 1ull;
+              p0[u] = readlane64(cur, l[u]);
+              pend[u] = readlane64(end, l[u]);
+              a[u] = readlane_f64(av, l[u]);
+              rem[u] = on[u] ? (uint32_t)min(pend[u] - p0[u], (uint64_t)64) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const bool have = lane < rem[u];
+              col[u] = have ? B.col[p0[u] + lane] : EMPTY_KEY;
+              v[u] = have ? B.val[p0[u] + lane] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              in[u] = lane < rem[u] && (uint64_t)col[u] < chi;
+              pos[u] = find(in[u] ? col[u] : 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (!on[u]) continue; // wave-uniform
+              if (in[u]) lds_add_f64(&vals[pos[u]], __dmul_rn(a[u], v[u]));
+              uint32_t took = (uint32_t)__popcll(__ballot(in[u]));
+              uint64_t ncur = p0[u] + took;
+              uint64_t notin = __ballot(lane < rem[u] && !in[u]);
+              uint32_t nxt = EMPTY_KEY;
+              if (notin) {
+                nxt = (uint32_t)__builtin_amdgcn_readlane((int)col[u], (int)__builtin_ctzll(notin));
+              } else {
+                while (ncur < pend[u]) { // the whole block belonged to the chunk and the B row goes on
+                  const uint32_t r2 = (uint32_t)min(pend[u] - ncur, (uint64_t)64);
+                  const bool have = lane < r2;
+                  const uint32_t c2 = have ? B.col[ncur + lane] : EMPTY_KEY;
+                  const double v2 = have ? B.val[ncur + lane] : 0.0;
+                  const bool in2 = have && (uint64_t)c2 < chi;
+                  if (in2) lds_add_f64(&vals[find(c2)], __dmul_rn(a[u], v2));
+                  took = (uint32_t)__popcll(__ballot(in2));
+                  ncur += took;
+                  notin = __ballot(have && !in2);
+                  if (notin) {
+                    nxt = (uint32_t)__builtin_amdgcn_readlane((int)c2, (int)__builtin_ctzll(notin));
+                    break;
+                  }
+                }
+              }
+              if (lane == l[u]) { cur = ncur; nextc = nxt; }
             }
           }
         } else {
-          // short pieces: products laid end to end over the lanes, conflicts resolved in lane order
+          // short pieces: products laid end to end over the lanes, conflicts resolved in lane order.
+          // A piece's entries are distinct columns of this chunk: at most ncols, at most chi - nextc;
+          // the three entries after the first are looked at directly, a longer piece is searched.
+          uint32_t cnt = 0;
+          uint64_t slo = 0, shi = 0;
+          if (act) {
+            const uint64_t lim = min(end, cur + min((uint64_t)ncols, chi - nextc));
+            const uint32_t c1 = cur + 1 < lim ? B.col[cur + 1] : EMPTY_KEY;
+            const uint32_t c2 = cur + 2 < lim ? B.col[cur + 2] : EMPTY_KEY;
+            const uint32_t c3 = cur + 3 < lim ? B.col[cur + 3] : EMPTY_KEY;
+            const bool i1 = cur + 1 < lim && (uint64_t)c1 < chi;
+            const bool i2 = i1 && cur + 2 < lim && (uint64_t)c2 < chi;
+            const bool i3 = i2 && cur + 3 < lim && (uint64_t)c3 < chi;
+            cnt = 1u + (i1 ? 1u : 0u) + (i2 ? 1u : 0u) + (i3 ? 1u : 0u);
+            if (i3 && cur + 4 < lim) { slo = cur + 4; shi = lim; }
+          }
+          const bool searched = slo < shi;
+          const uint64_t found = lower_bound_col(B.col, slo, shi, chi);
+          if (searched) cnt = (uint32_t)(found - cur);
+          const uint32_t incl = group_incl_scan<64>(cnt);
+          const uint32_t total = group_last<64>(incl);
           lds_fence();
           st[lane] = incl - cnt;
           p0s[lane] = cur;
@@ -1575,10 +1784,56 @@ __global__ void __launch_bounds__(64)
             const uint32_t pos = valid ? find(col) : 0u;
             claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[tt], bv));
           }
+          cur += cnt;
+          if (act) nextc = cur < end ? B.col[cur] : EMPTY_KEY;
         }
-        cur += cnt;
-        nextc = cur < end ? B.col[cur] : EMPTY_KEY;
-        if (!in_regs && act) { l_cur[e] = cur; l_next[e] = nextc; }
+      };
+      if (in_regs) {
+        const bool act = cur < end && (uint64_t)nextc < chi;
+        if (__any(act)) block(act, cur, end, av, nextc);
+      } else {
+        // The list entries that have something in this chunk are gathered, in list order, in a
+        // ring of 128 indices in LDS, and taken from it 64 at a time.
+        uint32_t head = 0, count = 0;
+        auto take = [&](uint32_t ntake) {
+          bool have = lane < ntake;
+          uint32_t e = have ? ring[(head + lane) & 127u] : 0u;
+          if (e >= nlist) { e = 0u; if (have) o.zero_count[3] = 1ull; have = false; }
+          uint64_t ecur = have ? l_cur[e] : 0ull;
+          const uint64_t eend = have ? l_end[e] : 0ull;
+          const double eav = have ? l_av[e] : 0.0;
+          uint32_t enext = have ? l_next[e] : EMPTY_KEY;
+          if (have && !(ecur < eend && eend <= nnz_b && (uint64_t)enext < chi)) {
+            o.zero_count[3] = 1ull; // an entry that cannot be: reported by the host, never followed
+            have = false;
+          }
+          block(have, ecur, eend, eav, enext);
+          if (have) { l_cur[e] = ecur; l_next[e] = enext; }
+          head += ntake;
+          count -= ntake;
+        };
+        for (uint32_t lb = 0; lb < nlist; lb += 64 * U) {
+          uint32_t nx[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t e = lb + 64u * u + lane;
+            nx[u] = e < nlist ? l_next[e] : EMPTY_KEY;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool a = nx[u] != EMPTY_KEY && (uint64_t)nx[u] < chi; // chi is 2^32 in a row's last chunk
+            const uint64_t mask = __ballot(a);
+            if (!mask) continue;
+            if (a) ring[(head + count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & 127u] = lb + 64u * u + lane;
+            count += (uint32_t)__popcll(mask);
+            lds_fence();
+            if (count >= 64u) take(64u);
+          }
+        }
+        if (count) take(count);
+        // the list is read back by other lanes in the next chunk: all its stores have to be done
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       lds_fence();
       for (uint32_t p = lane; p < ncols; p += 64) {

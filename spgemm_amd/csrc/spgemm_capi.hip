@@ -82,7 +82,7 @@ struct spgemm_ctx {
   Growable temp_cols; // sorted structural columns (symbolic -> numeric)
   Growable gscratch;  // bitmap scratch of the global path (kept zero between uses)
   size_t gscratch_zeroed = 0;
-  Growable big_cur;   // big-row symbolic: one cursor per A entry (rows longer than BIG_CUR)
+  Growable big_cur;   // big-row symbolic: {position, end} per A entry (rows longer than BIG_CUR)
   Growable slice_buf; // big-row numeric: item counts, offsets, items, per-workgroup lists
   uint32_t big_rows = 1;         // big rows of a sorted B: LDS bitmap windows / output slices
   uint32_t slice_blocks = 0;     // workgroups of the slice kernel (0: fill the device)
@@ -736,12 +736,12 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     } else if (b_sorted && ctx->big_rows) {
       // windows of up to 2^20 columns (128 KiB of LDS); a narrower matrix gets one window
       uint32_t win_words = (uint32_t)std::min<uint64_t>(ctx->big_win_words, align_up((B->cols + 31) / 32, BIG_THREADS));
-      size_t lds = ((size_t)pad33(win_words) + BIG_CUR) * 4;
-      if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 4));
+      size_t lds = sym_big_lds(win_words);
+      if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 16));
       st.rows_global += cnt;
       TRY(prof_begin(ctx, 0, 2, 64, cnt, win_words, 0, lds, rows_bin));
       hipLaunchKernelGGL(k_sym_big, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, win_words,
-                         reinterpret_cast<uint32_t *>(ctx->big_cur.p));
+                         reinterpret_cast<uint64_t *>(ctx->big_cur.p), A->nnz);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
@@ -861,10 +861,10 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       // items = runs of chunks of SLICE_W outputs; at most one per chunk
       const uint64_t max_items = nnz_structural / SLICE_W + cnt;
       uint32_t blocks = ctx->slice_blocks ? ctx->slice_blocks : (uint32_t)ctx->cu_count * (uint32_t)(lds_max / SLICE_LDS);
-      blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)4 << 30) / (list_cap * 28)));
+      blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)4 << 30) / (list_cap * SLICE_ENTRY_BYTES)));
       const size_t b_count = align_up((size_t)cnt * 4, 256), b_off = align_up(((size_t)cnt + 1) * 8, 256);
       const size_t b_items = align_up(max_items * sizeof(SliceItem), 256);
-      const size_t b_lists = (size_t)blocks * list_cap * 28;
+      const size_t b_lists = (size_t)blocks * list_cap * SLICE_ENTRY_BYTES;
       TRY(grow(ctx, ctx->slice_buf, b_count + b_off + b_items + b_lists));
       char *sb = reinterpret_cast<char *>(ctx->slice_buf.p);
       uint32_t *s_count = reinterpret_cast<uint32_t *>(sb);
@@ -878,7 +878,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       hipLaunchKernelGGL(k_slice_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
                          pl.r_nnz, s_off, s_items);
       hipLaunchKernelGGL(k_num_slice, dim3(blocks), dim3(64), SLICE_LDS, ctx->stream, s_items, s_off + cnt, cA, cB, rm, no,
-                         zero_count + 1, s_lists, list_cap);
+                         zero_count + 1, s_lists, list_cap, B->nnz);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
@@ -897,7 +897,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
   TRY(prof_collect(ctx, A, pl.r_nnz, 1));
   HIP_TRY(hipMemcpyAsync(&hc->total_a, zero_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->total_nprod, zero_count + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (hc->total_nprod) return fail(SPGEMM_ERR_STATE, "internal: the big-row numeric kernel met a damaged work list");
   uint64_t zeros = hc->total_a;
   if (zeros) {
     // Entries that summed to exactly 0.0 are dropped, as Cells::add erases them
