@@ -1473,7 +1473,7 @@ __global__ void __launch_bounds__(256)
 // entries per workgroup).  A chunk then looks only at the list's `next column` to find the entries
 // it has to touch, and advances their positions for the chunk that follows.
 constexpr uint32_t SLICE_W = 1024;
-constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES + 512u; // cols u32 | vals f64 | owner u32 | flat-walk scratch | ring
+constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES; // cols u32 | vals f64 | owner u32 | flat-walk scratch
 
 struct SliceItem {
   uint32_t row, c0, nc; // chunks [c0, c0 + nc) of the row
@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ c
 // `work`: [0] = next item to hand out (zero on entry), total = n_items[0].  o.zero_count[3] is set
 // when a list entry read back from scratch is not a position inside B (never seen; it would mean
 // that the list was damaged) - the entry is skipped and the host reports the multiply as failed.
-// list_scratch: per workgroup, list_cap entries of {cur u64 | end u64 | av f64 | next u32 | pad}.
+// list_scratch: per workgroup, list_cap entries of {cur u64 | end u64 | av f64 | next u32 | queue u32}.
 constexpr uint32_t SLICE_ENTRY_BYTES = 32;
 __global__ void __launch_bounds__(64)
     k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
@@ -1570,12 +1570,12 @@ __global__ void __launch_bounds__(64)
   uint32_t *st = reinterpret_cast<uint32_t *>(flat);
   uint64_t *p0s = reinterpret_cast<uint64_t *>(flat + 256);
   double *avs = reinterpret_cast<double *>(flat + 768);
-  uint32_t *ring = reinterpret_cast<uint32_t *>(flat + FLAT_BYTES); // 128 list indices
   const uint32_t lane = threadIdx.x;
   uint64_t *l_cur = reinterpret_cast<uint64_t *>(list_scratch + (size_t)blockIdx.x * list_cap * SLICE_ENTRY_BYTES);
   uint64_t *l_end = l_cur + list_cap;
   double *l_av = reinterpret_cast<double *>(l_end + list_cap);
   uint32_t *l_next = reinterpret_cast<uint32_t *>(l_av + list_cap);
+  uint32_t *l_q = l_next + list_cap;
   const uint64_t total_items = n_items[0];
   for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
   uint32_t stamp = 0;
@@ -1793,25 +1793,9 @@ __global__ void __launch_bounds__(64)
         if (__any(act)) block(act, cur, end, av, nextc);
       } else {
         // The list entries that have something in this chunk are gathered, in list order, in a
-        // ring of 128 indices in LDS, and taken from it 64 at a time.
-        uint32_t head = 0, count = 0;
-        auto take = [&](uint32_t ntake) {
-          bool have = lane < ntake;
-          uint32_t e = have ? ring[(head + lane) & 127u] : 0u;
-          if (e >= nlist) { e = 0u; if (have) o.zero_count[3] = 1ull; have = false; }
-          uint64_t ecur = have ? l_cur[e] : 0ull;
-          const uint64_t eend = have ? l_end[e] : 0ull;
-          const double eav = have ? l_av[e] : 0.0;
-          uint32_t enext = have ? l_next[e] : EMPTY_KEY;
-          if (have && !(ecur < eend && eend <= nnz_b && (uint64_t)enext < chi)) {
-            o.zero_count[3] = 1ull; // an entry that cannot be: reported by the host, never followed
-            have = false;
-          }
-          block(have, ecur, eend, eav, enext);
-          if (have) { l_cur[e] = ecur; l_next[e] = enext; }
-          head += ntake;
-          count -= ntake;
-        };
+        // queue (global scratch, written here and read back by other lanes after a fence), and
+        // taken from it 64 at a time.
+        uint32_t nq = 0;
         for (uint32_t lb = 0; lb < nlist; lb += 64 * U) {
           uint32_t nx[U];
 #pragma unroll
@@ -1823,14 +1807,27 @@ __global__ void __launch_bounds__(64)
           for (int u = 0; u < U; ++u) {
             const bool a = nx[u] != EMPTY_KEY && (uint64_t)nx[u] < chi; // chi is 2^32 in a row's last chunk
             const uint64_t mask = __ballot(a);
-            if (!mask) continue;
-            if (a) ring[(head + count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & 127u] = lb + 64u * u + lane;
-            count += (uint32_t)__popcll(mask);
-            lds_fence();
-            if (count >= 64u) take(64u);
+            if (a) l_q[nq + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = lb + 64u * u + lane;
+            nq += (uint32_t)__popcll(mask);
           }
         }
-        if (count) take(count);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t qb = 0; qb < nq; qb += 64) {
+          bool have = qb + lane < nq;
+          uint32_t e = have ? l_q[qb + lane] : 0u;
+          if (e >= nlist) { e = 0u; if (have) o.zero_count[3] = 1ull; have = false; }
+          uint64_t ecur = have ? l_cur[e] : 0ull;
+          const uint64_t eend = have ? l_end[e] : 0ull;
+          const double eav = have ? l_av[e] : 0.0;
+          uint32_t enext = have ? l_next[e] : EMPTY_KEY;
+          if (have && !(ecur < eend && eend <= nnz_b && (uint64_t)enext < chi)) {
+            o.zero_count[3] = 1ull; // an entry that cannot be: reported by the host, never followed
+            have = false;
+          }
+          block(have, ecur, eend, eav, enext);
+          if (have) { l_cur[e] = ecur; l_next[e] = enext; }
+        }
         // the list is read back by other lanes in the next chunk: all its stores have to be done
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
