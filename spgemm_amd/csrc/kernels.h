@@ -1051,7 +1051,6 @@ __global__ void __launch_bounds__(BIG_THREADS)
   uint32_t *s_long = s_mid + BIG_CUR;
   uint32_t *s_cnt = s_long + BIG_CUR;
   uint32_t *s_blk = s_cnt + BIG_CUR; // per block of 64 words: set bits, then offset of its first column
-  __shared__ uint32_t s_wsum[BIG_WAVES];
   __shared__ uint32_t s_n[2]; // mid pieces, long pieces of the current batch
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -1064,14 +1063,16 @@ __global__ void __launch_bounds__(BIG_THREADS)
   uint32_t *out = m.temp_cols + m.t_off[row];
   uint32_t carry = 0;
   if (tid < 2) s_n[tid] = 0u;
+  __syncthreads();
   for (uint32_t wb = w0; wb <= w1; wb += win_words) {
     const uint32_t nw = min(win_words, w1 + 1u - wb);
     const uint32_t nblk = (nw + 255u) >> 8;
     const bool first = wb == w0, last = wb + nw > w1;
     const uint64_t chi = (uint64_t)(wb + nw) << 5;
-    for (uint32_t w = tid * 4u; w < nblk * 256u; w += BIG_THREADS * 4u)
-      *reinterpret_cast<uint4 *>(&bits[w]) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
+    if (first) { // later windows find the bitmap cleared by the write-out of the one before
+      for (uint32_t w = tid * 4u; w < win_words; w += BIG_THREADS * 4u)
+        *reinterpret_cast<uint4 *>(&bits[w]) = make_uint4(0u, 0u, 0u, 0u);
+    }
     for (uint32_t kb = 0; kb < len_a; kb += BIG_CUR) {
       // classify what is left of every B row of this batch of A entries
       const uint32_t idx = kb + tid;
@@ -1160,9 +1161,10 @@ __global__ void __launch_bounds__(BIG_THREADS)
       __syncthreads();
       if (tid < nlong) pos[s_long[tid]] += s_cnt[tid];
       if (tid < 2) s_n[tid] = 0u;
-      __syncthreads();
+      if (kb + BIG_CUR < len_a) __syncthreads(); // the lists are filled again by the next batch
     }
-    // set bits per block of 256 words (four per lane); the words stay in registers for the write-out
+    // set bits per block of 256 words (four per lane); the words move to registers for the
+    // write-out and the bitmap is cleared for the next window
     uint4 wd[BIG_BPW];
     uint32_t ex[BIG_BPW];
 #pragma unroll
@@ -1171,34 +1173,33 @@ __global__ void __launch_bounds__(BIG_THREADS)
       wd[i] = make_uint4(0u, 0u, 0u, 0u);
       ex[i] = 0u;
       if (b < nblk) { // wave-uniform
-        wd[i] = *reinterpret_cast<const uint4 *>(&bits[b * 256u + lane * 4u]);
+        uint4 *src = reinterpret_cast<uint4 *>(&bits[b * 256u + lane * 4u]);
+        wd[i] = *src;
         const uint32_t pc = __popc(wd[i].x) + __popc(wd[i].y) + __popc(wd[i].z) + __popc(wd[i].w);
         uint32_t incl = 0;
-        if (__ballot(pc != 0u)) incl = group_incl_scan<64>(pc);
+        if (__ballot(pc != 0u)) {
+          incl = group_incl_scan<64>(pc);
+          *src = make_uint4(0u, 0u, 0u, 0u);
+        }
         ex[i] = incl - pc;
         if (lane == 63) s_blk[b] = incl;
       }
     }
     __syncthreads();
-    // exclusive scan over the blocks (nblk <= 128): one block per thread
-    const uint32_t bc = tid < nblk ? s_blk[tid] : 0u;
-    const uint32_t incl = group_incl_scan<64>(bc);
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < BIG_WAVES; ++i) {
-      const uint32_t v = s_wsum[i];
-      base += i < wv ? v : 0u;
-      tot += v;
-    }
-    if (tid < nblk) s_blk[tid] = carry + base + incl - bc;
-    __syncthreads();
+    // every wavefront scans the block totals for itself (nblk <= 128: two per lane)
+    const uint32_t t0 = 2u * lane < nblk ? s_blk[2u * lane] : 0u;
+    const uint32_t t1 = 2u * lane + 1u < nblk ? s_blk[2u * lane + 1u] : 0u;
+    const uint32_t pair_incl = group_incl_scan<64>(t0 + t1);
+    const uint32_t tot = group_last<64>(pair_incl);
+    const uint32_t pair_excl = pair_incl - (t0 + t1); // offset of block 2 * lane
 #pragma unroll
     for (uint32_t i = 0; i < BIG_BPW; ++i) {
       const uint32_t b = wv + BIG_WAVES * i;
       if (b >= nblk) break;
-      uint32_t at = s_blk[b] + ex[i];
+      // block b is held by lane b / 2 (b is wave-uniform)
+      const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)pair_excl, (int)(b >> 1)) +
+                            ((b & 1u) ? (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)(b >> 1)) : 0u);
+      uint32_t at = carry + boff + ex[i];
       const uint32_t cbase = (wb + b * 256u + lane * 4u) << 5;
       const uint32_t w4[4] = {wd[i].x, wd[i].y, wd[i].z, wd[i].w};
 #pragma unroll
@@ -1211,7 +1212,7 @@ __global__ void __launch_bounds__(BIG_THREADS)
       }
     }
     carry += tot;
-    __syncthreads(); // the bitmap, s_blk and s_wsum are reused by the next window
+    __syncthreads(); // s_blk and the lists are reused by the next window
   }
   if (tid == 0) {
     m.nnz[row] = carry;
