@@ -88,7 +88,17 @@ int spgemm_ctx_device(const spgemm_ctx *ctx, int *device);
  * hipStreamLegacy, not NULL. */
 int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
 int spgemm_synchronize(spgemm_ctx *ctx);
-/* Tunables, by name (e.g. "window_max_span", "lanes_scale"); unknown names are an error. */
+/* Tunables, by name; unknown names are an error.
+ *   window_max_span, window_ratio, hash_max_nprod   row binning (window / LDS hash / big rows)
+ *   g_thresh0, g_thresh1, g_thresh2                 mean B-row length classes; <= g_thresh2: flat walk
+ *   flat_walk, row_groups, big_rows                 0/1 switches of the flat walk, of the grouping of
+ *                                                   identical A rows, of the big-row kernels (B sorted)
+ *   lds_budget                                      LDS bytes per workgroup aimed for
+ *   big_win_words                                   bitmap window of the big-row symbolic kernel
+ *                                                   (32-column words, multiple of 1024, <= 32768)
+ *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)
+ *   global_blocks_sym, global_blocks_num            workgroups of the unsorted-B fallback kernels
+ *   profile_launches                                0 off, 1 HIP events per launch, 2 + per-launch sums */
 int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value);
 
 /* ---- matrices: replace matrix::ManagedCSRMatrix / CSRMatrix
