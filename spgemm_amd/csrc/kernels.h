@@ -1582,11 +1582,20 @@ __global__ void __launch_bounds__(64)
   uint32_t stamp = 0;
   uint32_t nz = 0;
   constexpr int U = 4; // B row pieces whose loads and column searches are in flight together
+#ifdef SG_SLICE_STAMPS
+  // diagnostic build: cycles per phase, summed over the wavefronts into o.zero_count[8..]
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define SG_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define SG_STAMP(i)
+#endif
   for (;;) {
     unsigned long long t = 0;
     if (lane == 0) t = atomicAdd(work, 1ull);
     t = readlane64(t, 0);
     if (t >= total_items) break;
+    SG_STAMP(0)
     const SliceItem it = items[t];
     const uint32_t row = it.row;
     const uint32_t n = m.nnz[row];
@@ -1653,6 +1662,7 @@ __global__ void __launch_bounds__(64)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    SG_STAMP(1)
     // -- the chunks
     for (uint32_t c = it.c0; c < it.c0 + it.nc; ++c) {
       const uint32_t pbase = c * SLICE_W;
@@ -1661,15 +1671,25 @@ __global__ void __launch_bounds__(64)
       const uint64_t chi = chunk_last ? chi_item : (uint64_t)tin[(size_t)pbase + SLICE_W];
       const uint32_t chunks_left = chunks - c;
       lds_fence();
-      for (uint32_t p = lane; p < SLICE_W; p += 64) {
-        scol[p] = p < ncols ? tin[(size_t)pbase + p] : EMPTY_KEY;
-        vals[p] = 0.0;
+      {
+        uint32_t tc[SLICE_W / 64]; // the chunk's columns: all loads in flight before the first LDS store
+#pragma unroll
+        for (uint32_t i = 0; i < SLICE_W / 64; ++i) {
+          const uint32_t p = i * 64u + lane;
+          tc[i] = p < ncols ? tin[(size_t)pbase + p] : EMPTY_KEY;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < SLICE_W / 64; ++i) {
+          scol[i * 64u + lane] = tc[i];
+          vals[i * 64u + lane] = 0.0;
+        }
       }
       if (stamp > (1u << 25)) { // claims compare tags: start over before the stamp field overflows
         for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
         stamp = 0;
       }
       lds_fence();
+      SG_STAMP(2)
       auto find = [&](uint32_t col) { // position of a column that is in the chunk
         uint32_t pos = 0;
 #pragma unroll
@@ -1684,54 +1704,66 @@ __global__ void __launch_bounds__(64)
         const uint32_t nact = (uint32_t)__popcll(amask);
         // expected length of a piece: what is left of the B row, spread over the chunks that follow
         const uint32_t est = act ? (uint32_t)min(end - cur, (uint64_t)SLICE_W) / chunks_left : 0u;
+        SG_STAMP(3)
         if (group_sum<64>(est) >= 16u * nact) {
           // long pieces: one B row at a time, its entries over the lanes (distinct columns: no
           // conflicts); U pieces are loaded and searched together, then added in A order
-          uint64_t mask = amask;
-          while (mask) {
-            uint32_t l[U], rem[U], col[U], pos[U];
+          // group = U pieces; the loads of the next group fly while this one is searched and added
+          struct Group {
+            uint32_t l[U], rem[U], col[U];
             uint64_t p0[U], pend[U];
             double a[U], v[U];
-            bool on[U], in[U];
+            bool on[U];
+          };
+          uint64_t mask = amask;
+          auto fetch = [&](Group &g) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              on[u] = mask != 0;
-              l[u] = on[u] ? (uint32_t)__builtin_ctzll(mask) : 0u;
-              if (on[u]) mask &= mask - 1ull;
-              p0[u] = readlane64(cur, l[u]);
-              pend[u] = readlane64(end, l[u]);
-              a[u] = readlane_f64(av, l[u]);
-              rem[u] = on[u] ? (uint32_t)min(pend[u] - p0[u], (uint64_t)64) : 0u;
+              g.on[u] = mask != 0;
+              g.l[u] = g.on[u] ? (uint32_t)__builtin_ctzll(mask) : 0u;
+              if (g.on[u]) mask &= mask - 1ull;
+              g.p0[u] = readlane64(cur, g.l[u]);
+              g.pend[u] = readlane64(end, g.l[u]);
+              g.a[u] = readlane_f64(av, g.l[u]);
+              g.rem[u] = g.on[u] ? (uint32_t)min(g.pend[u] - g.p0[u], (uint64_t)64) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              const bool have = lane < rem[u];
-              col[u] = have ? B.col[p0[u] + lane] : EMPTY_KEY;
-              v[u] = have ? B.val[p0[u] + lane] : 0.0;
+              const bool have = lane < g.rem[u];
+              g.col[u] = have ? B.col[g.p0[u] + lane] : EMPTY_KEY;
+              g.v[u] = have ? B.val[g.p0[u] + lane] : 0.0;
+            }
+          };
+          Group g, gn;
+          fetch(g);
+          while (g.on[0]) {
+            gn.on[0] = false;
+            if (mask) fetch(gn); // other lanes' pieces: not touched by what follows
+            uint32_t pos[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              in[u] = lane < g.rem[u] && (uint64_t)g.col[u] < chi;
+              pos[u] = find(in[u] ? g.col[u] : 0u);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              in[u] = lane < rem[u] && (uint64_t)col[u] < chi;
-              pos[u] = find(in[u] ? col[u] : 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              if (!on[u]) continue; // wave-uniform
-              if (in[u]) lds_add_f64(&vals[pos[u]], __dmul_rn(a[u], v[u]));
+              if (!g.on[u]) continue; // wave-uniform
+              if (in[u]) lds_add_f64(&vals[pos[u]], __dmul_rn(g.a[u], g.v[u]));
               uint32_t took = (uint32_t)__popcll(__ballot(in[u]));
-              uint64_t ncur = p0[u] + took;
-              uint64_t notin = __ballot(lane < rem[u] && !in[u]);
+              uint64_t ncur = g.p0[u] + took;
+              uint64_t notin = __ballot(lane < g.rem[u] && !in[u]);
               uint32_t nxt = EMPTY_KEY;
               if (notin) {
-                nxt = (uint32_t)__builtin_amdgcn_readlane((int)col[u], (int)__builtin_ctzll(notin));
+                nxt = (uint32_t)__builtin_amdgcn_readlane((int)g.col[u], (int)__builtin_ctzll(notin));
               } else {
-                while (ncur < pend[u]) { // the whole block belonged to the chunk and the B row goes on
-                  const uint32_t r2 = (uint32_t)min(pend[u] - ncur, (uint64_t)64);
+                while (ncur < g.pend[u]) { // the whole block belonged to the chunk and the B row goes on
+                  const uint32_t r2 = (uint32_t)min(g.pend[u] - ncur, (uint64_t)64);
                   const bool have = lane < r2;
                   const uint32_t c2 = have ? B.col[ncur + lane] : EMPTY_KEY;
                   const double v2 = have ? B.val[ncur + lane] : 0.0;
                   const bool in2 = have && (uint64_t)c2 < chi;
-                  if (in2) lds_add_f64(&vals[find(c2)], __dmul_rn(a[u], v2));
+                  if (in2) lds_add_f64(&vals[find(c2)], __dmul_rn(g.a[u], v2));
                   took = (uint32_t)__popcll(__ballot(in2));
                   ncur += took;
                   notin = __ballot(have && !in2);
@@ -1741,20 +1773,23 @@ __global__ void __launch_bounds__(64)
                   }
                 }
               }
-              if (lane == l[u]) { cur = ncur; nextc = nxt; }
+              if (lane == g.l[u]) { cur = ncur; nextc = nxt; }
             }
+            g = gn;
           }
+          SG_STAMP(4)
         } else {
           // short pieces: products laid end to end over the lanes, conflicts resolved in lane order.
           // A piece's entries are distinct columns of this chunk: at most ncols, at most chi - nextc;
           // the three entries after the first are looked at directly, a longer piece is searched.
           uint32_t cnt = 0;
-          uint64_t slo = 0, shi = 0;
+          uint64_t slo = 0, shi = 0, lim = 0;
+          uint32_t c1 = EMPTY_KEY, c2 = EMPTY_KEY, c3 = EMPTY_KEY;
           if (act) {
-            const uint64_t lim = min(end, cur + min((uint64_t)ncols, chi - nextc));
-            const uint32_t c1 = cur + 1 < lim ? B.col[cur + 1] : EMPTY_KEY;
-            const uint32_t c2 = cur + 2 < lim ? B.col[cur + 2] : EMPTY_KEY;
-            const uint32_t c3 = cur + 3 < lim ? B.col[cur + 3] : EMPTY_KEY;
+            lim = min(end, cur + min((uint64_t)ncols, chi - nextc));
+            c1 = cur + 1 < end ? B.col[cur + 1] : EMPTY_KEY;
+            c2 = cur + 2 < end ? B.col[cur + 2] : EMPTY_KEY;
+            c3 = cur + 3 < end ? B.col[cur + 3] : EMPTY_KEY;
             const bool i1 = cur + 1 < lim && (uint64_t)c1 < chi;
             const bool i2 = i1 && cur + 2 < lim && (uint64_t)c2 < chi;
             const bool i3 = i2 && cur + 3 < lim && (uint64_t)c3 < chi;
@@ -1771,22 +1806,35 @@ __global__ void __launch_bounds__(64)
           p0s[lane] = cur;
           avs[lane] = av;
           lds_fence();
-          for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-            const uint32_t q = q0 + lane;
+          auto fetchq = [&](uint32_t q, uint32_t &tt, uint32_t &col, double &bv) {
             const bool valid = q < total;
             const uint32_t qq = valid ? q : 0u;
-            uint32_t tt = 0;
+            tt = 0;
 #pragma unroll
             for (uint32_t sft = 32; sft > 0; sft >>= 1)
               if (st[tt + sft] <= qq) tt += sft;
             const uint64_t p = p0s[tt] + (qq - st[tt]);
-            const uint32_t col = valid ? B.col[p] : EMPTY_KEY;
-            const double bv = valid ? B.val[p] : 0.0;
-            const uint32_t pos = valid ? find(col) : 0u;
-            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[tt], bv));
+            col = valid ? B.col[p] : EMPTY_KEY;
+            bv = valid ? B.val[p] : 0.0;
+          };
+          uint32_t t_c = 0, col_c = EMPTY_KEY;
+          double bv_c = 0.0;
+          if (total) fetchq(lane, t_c, col_c, bv_c);
+          for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+            uint32_t t_n = 0, col_n = EMPTY_KEY;
+            double bv_n = 0.0;
+            if (q0 + 64 < total) fetchq(q0 + 64 + lane, t_n, col_n, bv_n); // flies during this step
+            const bool valid = col_c != EMPTY_KEY;
+            const uint32_t pos = valid ? find(col_c) : 0u;
+            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[t_c], bv_c));
+            t_c = t_n; col_c = col_n; bv_c = bv_n;
           }
           cur += cnt;
-          if (act) nextc = cur < end ? B.col[cur] : EMPTY_KEY;
+          if (act) { // the next column is one of the three looked at, unless the piece was longer
+            const uint32_t seen = cnt == 1u ? c1 : cnt == 2u ? c2 : c3;
+            nextc = cur >= end ? EMPTY_KEY : cnt <= 3u ? seen : B.col[cur];
+          }
+          SG_STAMP(5)
         }
       };
       if (in_regs) {
@@ -1834,17 +1882,24 @@ __global__ void __launch_bounds__(64)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       }
       lds_fence();
+      SG_STAMP(3)
       for (uint32_t p = lane; p < ncols; p += 64) {
         const double v = vals[p];
         o.c_col[off + pbase + p] = scol[p];
         o.c_val[off + pbase + p] = v;
         nz += (v == 0.0) ? 1u : 0u;
       }
+      SG_STAMP(6)
     }
   }
+#ifdef SG_SLICE_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&o.zero_count[8 + i], tph[i]);
+#endif
   nz = group_sum<64>(nz);
   if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
+#undef SG_STAMP
 
 // numeric, global path: ONE wavefront per row (the k order must be kept), accumulating straight
 // into the row's slice of c_val through L2 atomics.  scratch: per workgroup `words_total`

@@ -900,6 +900,14 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   HIP_TRY(hipMemcpyAsync(&hc->total_nprod, zero_count + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (hc->total_nprod) return fail(SPGEMM_ERR_STATE, "internal: the big-row numeric kernel met a damaged work list");
+#ifdef SG_SLICE_STAMPS
+  {
+    unsigned long long ph[8];
+    HIP_TRY(hipMemcpy(ph, zero_count + 8, sizeof(ph), hipMemcpyDeviceToHost));
+    fprintf(stderr, "slice stamps (Mcycles, all waves): grab %.1f list %.1f fill %.1f scan/other %.1f per-row %.1f flat %.1f write %.1f\n",
+            ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6);
+  }
+#endif
   uint64_t zeros = hc->total_a;
   if (zeros) {
     // Entries that summed to exactly 0.0 are dropped, as Cells::add erases them
