@@ -178,6 +178,19 @@ int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B,
  *      reproducible. perm_out[i] = original index placed at position i. ------------------- */
 int spgemm_shuffle_random(uint32_t n, uint64_t seed, uint32_t *perm_out);
 
+/* Iterative locality shuffle: replaces partition::iterative_shuffle and its helpers
+ * calculate_avg_indices_row / _col (reference src/partition.cpp:73-202).  C is a device matrix
+ * whose PATTERN is used (the reference reads C_sparsity.mtx; here it is typically a product
+ * computed by spgemm_multiply).  Iteration i re-ranks the rows (i even) or the columns (i odd) by
+ * the mean position of their entries in the other dimension; `iterations` replaces the reference's
+ * wall-clock limit.  Means are exact (integer sum, one division in double) and ties go to the
+ * lower index, so the result is reproducible.  row_shuffle[i] / col_shuffle[j] = the original row /
+ * column at position i / j (what the reference saves as A_shuffle / B_shuffle); host arrays of
+ * C.rows / C.cols entries.  row_variance (optional, (iterations + 1) / 2 doubles) receives the
+ * variance of (mean - rank) after every row iteration, the figure the reference logs. */
+int spgemm_shuffle_iterative(spgemm_ctx *ctx, const spgemm_mat *C, uint32_t iterations, uint32_t *row_shuffle,
+                             uint32_t *col_shuffle, double *row_variance);
+
 /* ---- operand selection: what the reference's loader does with keep_rows / keep_cols
  *      (include/matrix_impl.hpp:163-221, src/main.cpp:213-217), on the device.
  *      keep_rows (HOST, may be NULL = all rows in order): output row r is input row

@@ -367,6 +367,59 @@ def merge_unshuffle(parts: Sequence[OCsr], partitions: Sequence[Partition], A_sh
 # Matrix Market (coordinate real general), enough for the fixtures
 # ---------------------------------------------------------------------------------------------
 
+def iterative_shuffle(C: OCsr, iterations: int):
+    """Iterative locality shuffle (reference src/partition.cpp:123-202 with its helpers :73-121),
+    restated with a fixed number of iterations instead of the reference's wall-clock limit
+    (:142-146), exact means (integer sum / count in float64; the reference adds float32 in storage
+    order) and ties broken by the lower index (the reference's parallel sort is not stable).
+    Even iterations re-rank the rows by the mean position of their columns, odd iterations the
+    columns by the mean position of their rows; an empty row or column gets the mean `cols`
+    (:83-84, :108-109).  Returns (row_shuffle, col_shuffle, row_variance): shuffle[i] = original
+    index at position i (:187-199); row_variance[i] = variance of (mean - rank) after row
+    iteration i (:169-178, with a true n / (n - 1) factor).  Parity of the permutation against the
+    reference binary is unpinned (the reference's own result depends on run time and thread
+    schedule); the GPU path is checked against this function."""
+    rows, cols = C.rows, C.cols
+    rp = C.row_ptr.astype(np.int64)
+    ci = C.col_idx.astype(np.int64)
+    rid = np.repeat(np.arange(rows, dtype=np.int64), np.diff(rp))
+    pos_r = np.arange(rows, dtype=np.int64)
+    pos_c = np.arange(cols, dtype=np.int64)
+    len_r = np.diff(rp)
+    len_c = np.bincount(ci, minlength=cols).astype(np.int64)
+    variances = []
+    for it in range(iterations):
+        if it % 2 == 0:
+            n, seg, other, lens = rows, rid, pos_c[ci], len_r
+        else:
+            n, seg, other, lens = cols, ci, pos_r[rid], len_c
+        if n == 0:
+            continue
+        sums = np.zeros(n, dtype=np.int64)
+        np.add.at(sums, seg, other)
+        mean = np.full(n, float(cols), dtype=np.float64)
+        nz = lens > 0
+        mean[nz] = sums[nz].astype(np.float64) / lens[nz].astype(np.float64)
+        order = np.argsort(mean, kind="stable")
+        rank = np.empty(n, dtype=np.int64)
+        rank[order] = np.arange(n, dtype=np.int64)
+        if it % 2 == 0:
+            pos_r = rank
+            x = mean[order] - np.arange(n, dtype=np.float64)
+            sx, sx2 = 0.0, 0.0
+            for v in x:  # the same order of additions as the host loop of the library
+                sx += v / n
+                sx2 += v * v / n
+            variances.append((sx2 - sx * sx) * (n / (n - 1)) if n > 1 else 0.0)
+        else:
+            pos_c = rank
+    row_shuffle = np.empty(rows, dtype=np.uint32)
+    row_shuffle[pos_r] = np.arange(rows, dtype=np.uint32)
+    col_shuffle = np.empty(cols, dtype=np.uint32)
+    col_shuffle[pos_c] = np.arange(cols, dtype=np.uint32)
+    return row_shuffle, col_shuffle, np.array(variances)
+
+
 def read_mtx(path: str) -> OCsr:
     with open(path, "r") as f:
         header = f.readline()

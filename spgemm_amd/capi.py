@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
     "spgemm_section_bitmap",
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
-    "spgemm_shuffle_random", "spgemm_mat_select",
+    "spgemm_shuffle_random", "spgemm_shuffle_iterative", "spgemm_mat_select",
     "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr",
     "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy",
 ]
@@ -112,6 +112,7 @@ def load() -> ctypes.CDLL:
         "spgemm_partition_balanced": (i32, [vp, u32, u32, i32, ctypes.POINTER(Partition)]),
         "spgemm_row_nprod": (i32, [vp, vp, vp, vp]),
         "spgemm_shuffle_random": (i32, [u32, u64, vp]),
+        "spgemm_shuffle_iterative": (i32, [vp, vp, u32, vp, vp, vp]),
         "spgemm_mat_select": (i32, [vp, vp, vp, u64, vp, u64, i32, pp]),
         "spgemm_section_nnz": (i32, [vp, vp, u32, u64, u64, vp]),
         "spgemm_pack_sections": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, vp, ctypes.POINTER(u64),
@@ -300,6 +301,17 @@ class Context:
         return [arr[i].as_dict() for i in range(n.value)]
 
     # -- bitmap / partition / shuffle ------------------------------------------------------------
+    def shuffle_iterative(self, C: DeviceCsr, iterations: int):
+        """Iterative locality shuffle of the pattern of C (reference src/partition.cpp:123-202).
+        Returns (row_shuffle, col_shuffle, row_variance)."""
+        rows, cols, _ = C.info()
+        rs = np.zeros(rows, dtype=np.uint32)
+        cs = np.zeros(cols, dtype=np.uint32)
+        var = np.zeros(max((iterations + 1) // 2, 1), dtype=np.float64)
+        _check(load().spgemm_shuffle_iterative(self.handle, C.handle, int(iterations), _np_ptr(rs), _np_ptr(cs),
+                                               _np_ptr(var)))
+        return rs, cs, var[:(iterations + 1) // 2]
+
     def section_bitmap(self, A: DeviceCsr, n_sections: int) -> np.ndarray:
         words = np.zeros((n_sections + 63) // 64, dtype=np.uint64)
         _check(load().spgemm_section_bitmap(self.handle, A.handle, n_sections, _np_ptr(words)))

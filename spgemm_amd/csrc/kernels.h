@@ -713,6 +713,10 @@ __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32
 // LDS scratch per wavefront: st[64] u32 | p0s[64] u64 | avs[64] f64 = FLAT_BYTES.
 // f(col, bval, aval, apos) is called by ALL lanes every step; col == EMPTY_KEY marks an idle lane.
 constexpr uint32_t FLAT_BYTES = 1280;
+#ifndef SG_FLAT_PF
+#define SG_FLAT_PF 3
+#endif
+constexpr int FLAT_PF = SG_FLAT_PF; // steps of the flat walk whose loads are in flight ahead of the consumed one
 
 template <bool WITH_VAL, class F>
 __device__ __forceinline__ void flat_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane,
@@ -750,19 +754,24 @@ __device__ __forceinline__ void flat_walk(const Csr &A, const Csr &B, uint32_t r
       c = valid ? B.col[p] : EMPTY_KEY;
       if constexpr (WITH_VAL) bv = valid ? B.val[p] : 0.0;
     };
-    uint32_t t_cur = 0, c_cur = EMPTY_KEY;
-    double bv_cur = 0.0;
-    if (total) fetch(lane, t_cur, c_cur, bv_cur);
+    // FLAT_PF steps are in flight ahead of the one that is consumed
+    uint32_t t_q[FLAT_PF], c_q[FLAT_PF];
+    double bv_q[FLAT_PF];
+#pragma unroll
+    for (int d = 0; d < FLAT_PF; ++d) {
+      t_q[d] = 0; c_q[d] = EMPTY_KEY; bv_q[d] = 0.0;
+      if (64u * d < total) fetch(64u * d + lane, t_q[d], c_q[d], bv_q[d]);
+    }
     for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-      uint32_t t_n = 0, c_n = EMPTY_KEY;
-      double bv_n = 0.0;
-      if (q0 + 64 < total) fetch(q0 + 64 + lane, t_n, c_n, bv_n); // next step's loads fly during this step
+      const uint32_t t_cur = t_q[0], c_cur = c_q[0];
+      const double bv_cur = bv_q[0];
+#pragma unroll
+      for (int d = 0; d + 1 < FLAT_PF; ++d) { t_q[d] = t_q[d + 1]; c_q[d] = c_q[d + 1]; bv_q[d] = bv_q[d + 1]; }
+      t_q[FLAT_PF - 1] = 0; c_q[FLAT_PF - 1] = EMPTY_KEY; bv_q[FLAT_PF - 1] = 0.0;
+      if (q0 + 64u * FLAT_PF < total) fetch(q0 + 64u * FLAT_PF + lane, t_q[FLAT_PF - 1], c_q[FLAT_PF - 1], bv_q[FLAT_PF - 1]);
       double av_cur = 0.0;
       if constexpr (WITH_VAL) av_cur = avs[t_cur];
       f(c_cur, bv_cur, av_cur, (uint32_t)(ab - a0) + t_cur);
-      t_cur = t_n;
-      c_cur = c_n;
-      bv_cur = bv_n;
     }
   }
 }

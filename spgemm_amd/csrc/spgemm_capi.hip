@@ -2,6 +2,7 @@
 // symbolic -> scan -> numeric pipeline, and the partition / bitmap / exchange helpers.
 #include "../../include/spgemm_amd.h"
 #include "kernels.h"
+#include "internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -371,6 +372,15 @@ extern "C" int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream) {
   ctx->plan.valid = false;
   return SPGEMM_OK;
 }
+
+extern "C" int spgemm_internal_stream(spgemm_ctx *ctx, hipStream_t *stream) {
+  if (!ctx || !stream) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  *stream = ctx->stream;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_internal_fail(int code, const char *message) { return fail(code, "%s", message); }
 
 extern "C" int spgemm_synchronize(spgemm_ctx *ctx) {
   if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");

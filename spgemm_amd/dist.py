@@ -49,10 +49,28 @@ def section_owner_bounds(n_sections: int, world: int) -> np.ndarray:
 
 
 def make_shuffles(n_rows: int, n_cols: int, impl: str, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Row / column permutations of a run: `shuffle` = seeded random (reference src/partition.cpp:15-37,
+    which is unseeded), anything else the identity."""
     from . import capi
     if impl == "shuffle":
         return capi.shuffle_random(n_rows, seed).astype(np.int64), capi.shuffle_random(n_cols, seed + 1).astype(np.int64)
     return np.arange(n_rows, dtype=np.int64), np.arange(n_cols, dtype=np.int64)
+
+
+def iterative_shuffles(ctx, A: HostCsr, B: HostCsr, iterations: int = 20) -> Tuple[np.ndarray, np.ndarray]:
+    """The reference's `iterative` shuffling (src/main.cpp:151-152, src/partition.cpp:123-202): the
+    pattern of C is computed here on the device (the reference reads C_sparsity.mtx)."""
+    dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    dB = dA if B is A else ctx.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
+    C = ctx.multiply(dA, dB)
+    try:
+        rs, cs, _ = ctx.shuffle_iterative(C, iterations)
+    finally:
+        C.free()
+        if dB is not dA:
+            dB.free()
+        dA.free()
+    return rs.astype(np.int64), cs.astype(np.int64)
 
 
 def select_rows(M: HostCsr, keep: np.ndarray) -> HostCsr:
@@ -114,6 +132,17 @@ def _staged(device, group=None) -> bool:
     import torch
     import torch.distributed as dist
     return torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+
+
+def _broadcast0(t_cpu, device, group=None):
+    """Broadcast of a host tensor from rank 0 (through the device when the backend needs it)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        dist.broadcast(t_cpu, src=0, group=group)
+        return t_cpu
+    d = t_cpu.to(device)
+    dist.broadcast(d, src=0, group=group)
+    return d.cpu()
 
 
 def _all_reduce(t, op=None, group=None):
@@ -249,7 +278,8 @@ class DistSpgemm:
     `result()` for the rank's rows of C."""
 
     def __init__(self, A: HostCsr, B: Optional[HostCsr], impl: str = "drop", n_sections: int = 512, seed: int = 1,
-                 partition: str = "naive", device_index: Optional[int] = None, group=None):
+                 partition: str = "naive", device_index: Optional[int] = None, group=None,
+                 shuffling: Optional[str] = None, shuffle_iterations: int = 20):
         import torch
         import torch.distributed as dist
         from . import capi
@@ -269,7 +299,24 @@ class DistSpgemm:
         # sections into the local B, and the multiply's kernels.
         self.stream = torch.cuda.Stream(device=self.device)
         self.ctx.set_stream(self.stream.cuda_stream)
-        self.A_shuffle, self.B_shuffle = make_shuffles(A.rows, B.cols, impl, seed)
+        # shuffling: None = what the impl implies (`shuffle` -> random), or the reference's
+        # shuffling argument none | random | iterative (src/main.cpp:143-152)
+        if shuffling not in (None, "none", "random", "iterative"):
+            raise ValueError("shuffling must be none, random or iterative")
+        if shuffling == "iterative":
+            # rank 0 computes the permutations, everybody receives them (src/main.cpp:202-205)
+            if self.rank == 0:
+                a_sh, b_sh = iterative_shuffles(self.ctx, A, B, shuffle_iterations)
+                both = torch.from_numpy(np.concatenate([a_sh, b_sh]))
+            else:
+                both = torch.empty(A.rows + B.cols, dtype=torch.int64)
+            if self.world > 1:
+                both = _broadcast0(both, self.device, group)
+            both = both.numpy()
+            self.A_shuffle, self.B_shuffle = both[:A.rows].copy(), both[A.rows:].copy()
+        else:
+            kind = impl if shuffling is None else ("shuffle" if shuffling == "random" else "none")
+            self.A_shuffle, self.B_shuffle = make_shuffles(A.rows, B.cols, kind, seed)
         if partition == "naive":
             self.partitions = capi.partition_naive(A.rows, B.cols, self.world)
         else:

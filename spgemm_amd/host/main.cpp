@@ -3,7 +3,7 @@
 //
 //   dphpc_amd <algo> <matrix> <run_path> <n_runs> <n_warmup> <shuffle> <partition>
 //             <parallel_load> <persist> <matrix_path>
-//             [--ranks P] [--gpus G] [--impl baseline|drop|shuffle] [--sections N] [--seed S]
+//             [--ranks P] [--gpus G] [--impl baseline|drop|shuffle] [--sections N] [--seed S] [--shuffle-iterations I]
 //
 // <algo>: baseline | outer (no section dropping) | drop | drop_parallel | drop_at_once |
 //         drop_at_once_parallel (bitmap-filtered exchange).  All run the same GPU operator; the
@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     int n_ranks = 0, n_gpus = 0;
     uint32_t n_sections = 512;
     uint64_t seed = 1;
+    uint32_t shuffle_iterations = 20; // of the iterative shuffle (the reference stops on wall clock)
     std::string impl;
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -46,6 +47,7 @@ int main(int argc, char **argv) {
       else if (a == "--impl") impl = next();
       else if (a == "--sections") n_sections = (uint32_t)std::stoul(next());
       else if (a == "--seed") seed = std::stoull(next());
+      else if (a == "--shuffle-iterations") shuffle_iterations = (uint32_t)std::stoul(next());
       else pos.push_back(a);
     }
     if (pos.size() < 10) {
@@ -106,7 +108,10 @@ int main(int argc, char **argv) {
     if (!(partition::load_shuffle(A_sh_saved, A_shuffle) && partition::load_shuffle(B_sh_saved, B_shuffle))) {
       if (shuffling_algo == "none") { A_shuffle = partition::identity(tA.nrows); B_shuffle = partition::identity(tB->ncols); }
       else if (shuffling_algo == "random") { A_shuffle = partition::shuffle(tA.nrows, seed); B_shuffle = partition::shuffle(tB->ncols, seed + 1); }
-      else if (shuffling_algo == "iterative") { std::cerr << "the iterative shuffle is not built yet\n"; return 1; }
+      else if (shuffling_algo == "iterative") {
+        matrix::ManagedCSRMatrix<> hA(tA, false, nullptr, nullptr), hB(*tB, false, nullptr, nullptr);
+        partition::iterative_shuffle(hA, hB, 0, shuffle_iterations, &A_shuffle, &B_shuffle);
+      }
       else { std::cerr << "Unknown shuffling algorithm type " << shuffling_algo << "\n"; return 1; }
     }
     measure_point(0, measure::shuffle, measure::MeasurementEvent::END);

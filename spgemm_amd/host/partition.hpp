@@ -5,8 +5,10 @@
 #include "../../include/spgemm_amd.h"
 #include "matrix.hpp"
 
+#include <cstring>
 #include <fstream>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,42 @@ inline Shuffle shuffle(size_t size, uint64_t seed) {
   Shuffle s(size);
   if (spgemm_shuffle_random((uint32_t)size, seed, s.data()) != SPGEMM_OK) throw std::runtime_error(spgemm_last_error());
   return s;
+}
+
+// Iterative locality shuffle (reference src/partition.cpp:123-202).  The reference reads the pattern
+// of C from C_sparsity.mtx; here C = A * B is computed on device `device` first.  `iterations`
+// replaces the reference's wall-clock limit.
+inline void iterative_shuffle(const matrix::CSRMatrix<double> &A, const matrix::CSRMatrix<double> &B, int device,
+                              uint32_t iterations, Shuffle *shuffled_rows, Shuffle *shuffled_cols) {
+  auto check = [](int rc) { if (rc != SPGEMM_OK) throw std::runtime_error(spgemm_last_error()); };
+  auto upload = [&](spgemm_ctx *ctx, const matrix::CSRMatrix<double> &m, spgemm_mat **out) {
+    std::vector<uint64_t> ptr(m.height + 1);
+    for (midx_t i = 0; i <= m.height; ++i) ptr[i] = m.row_ptr[i];
+    std::vector<double> val(m.non_zeros); // the blob's values may be 4-byte aligned only
+    std::memcpy(val.data(), m.values, (size_t)m.non_zeros * sizeof(double));
+    check(spgemm_mat_from_host(ctx, m.height, m.width, m.non_zeros, ptr.data(), m.col_idx, val.data(), out));
+  };
+  spgemm_ctx *ctx = nullptr;
+  check(spgemm_create(device, &ctx));
+  spgemm_mat *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  try {
+    upload(ctx, A, &dA);
+    upload(ctx, B, &dB);
+    check(spgemm_multiply(ctx, dA, dB, &dC));
+    shuffled_rows->assign(A.height, 0);
+    shuffled_cols->assign(B.width, 0);
+    check(spgemm_shuffle_iterative(ctx, dC, iterations, shuffled_rows->data(), shuffled_cols->data(), nullptr));
+  } catch (...) {
+    if (dC) spgemm_mat_free(ctx, dC);
+    if (dB) spgemm_mat_free(ctx, dB);
+    if (dA) spgemm_mat_free(ctx, dA);
+    spgemm_destroy(ctx);
+    throw;
+  }
+  spgemm_mat_free(ctx, dC);
+  spgemm_mat_free(ctx, dB);
+  spgemm_mat_free(ctx, dA);
+  spgemm_destroy(ctx);
 }
 
 inline Shuffle identity(size_t size) {

@@ -160,3 +160,67 @@ def test_dist_operator_ranks_share_one_gpu(world):
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert p.stdout.count("DIST_GPU_OK") == 4, p.stdout[-2000:]
+
+
+def _shuffled_band(n, seed):
+    """A banded matrix under ONE random permutation of rows and columns (P A P^T)."""
+    A = hostcsr.banded_random(n, 6, 30, seed=seed)
+    perm = np.random.default_rng(seed).permutation(n)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    return sd.relabel_cols(sd.select_rows(A, perm), inv)
+
+
+def _spread(C, rs, cs):
+    """mean |row position - column position| over the entries of C under the two shuffles"""
+    pos_r = np.empty(C.rows, dtype=np.int64)
+    pos_r[rs] = np.arange(C.rows)
+    pos_c = np.empty(C.cols, dtype=np.int64)
+    pos_c[cs] = np.arange(C.cols)
+    return float(np.abs(pos_r[C.row_ids()] - pos_c[C.col_idx.astype(np.int64)]).mean())
+
+
+@pytest.mark.parametrize("case", ["band", "rmat", "rect"])
+def test_iterative_shuffle_equals_oracle(case):
+    ctx = capi.Context(0)
+    if case == "band":
+        A = B = _shuffled_band(4000, 5)
+    elif case == "rmat":
+        A = B = hostcsr.rmat(11, 6, seed=2)
+    else:  # rectangular product with empty rows and columns in C
+        A = hostcsr.HostCsr.from_coo(700, 500, *np.random.default_rng(3).integers(0, [[700], [500]], (2, 1500)),
+                                     np.ones(1500), sum_duplicates=True).sorted_rows()
+        B = hostcsr.HostCsr.from_coo(500, 900, *np.random.default_rng(4).integers(0, [[500], [900]], (2, 1200)),
+                                     np.ones(1200), sum_duplicates=True).sorted_rows()
+    dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    dB = dA if B is A else ctx.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
+    dC = ctx.multiply(dA, dB)
+    E = orc.spgemm(to_o(A), to_o(B))
+    for iters in (0, 1, 2, 7):
+        rs, cs, var = ctx.shuffle_iterative(dC, iters)
+        ers, ecs, evar = orc.iterative_shuffle(E, iters)
+        assert np.array_equal(rs, ers) and np.array_equal(cs, ecs), (case, iters)
+        assert np.allclose(var, evar, rtol=1e-12, atol=0.0)
+        assert np.array_equal(np.sort(rs), np.arange(A.rows)) and np.array_equal(np.sort(cs), np.arange(B.cols))
+    if case == "band":  # the shuffle pulls C back towards a band
+        Ch = hostcsr.HostCsr(E.rows, E.cols, E.row_ptr, E.col_idx, E.val)
+        rs, cs, var = ctx.shuffle_iterative(dC, 40)
+        ident = np.arange(A.rows)
+        assert _spread(Ch, rs, cs) < 0.25 * _spread(Ch, ident, ident)
+        assert var[-1] < var[0]
+    for h in (dC, dA) + (() if dB is dA else (dB,)):
+        h.free()
+    ctx.close()
+
+
+def test_dist_operator_with_iterative_shuffling(pg):
+    A = _shuffled_band(5000, 8)
+    op = sd.DistSpgemm(A, None, impl="drop", n_sections=64, seed=5, device_index=0, shuffling="iterative",
+                       shuffle_iterations=10)
+    op.gemm()
+    M = sd.merge_unshuffle([op.result()], op.partitions, op.A_shuffle, op.B_shuffle, A.rows, A.cols)
+    E = orc.spgemm(to_o(A), to_o(A))
+    orc.assert_same(to_o(M), E, rtol=0.0)
+    ers, ecs, _ = orc.iterative_shuffle(E, 10)
+    assert np.array_equal(op.A_shuffle, ers) and np.array_equal(op.B_shuffle, ecs)
+    op.close()

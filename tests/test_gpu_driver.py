@@ -58,13 +58,18 @@ def test_config1_test_fixture_two_ranks_baseline(tmp_path, golden_dir):
 
 @pytest.mark.parametrize("ranks,algo,shuffle", [(1, "drop_parallel", "none"), (2, "drop_parallel", "none"),
                                                 (4, "drop_at_once_parallel", "none"), (4, "baseline", "none"),
-                                                (4, "drop", "random"), (3, "outer", "random")])
+                                                (4, "drop", "random"), (3, "outer", "random"),
+                                                (3, "drop", "iterative")])
 def test_first_fixture_all_variants(tmp_path, golden_dir, ranks, algo, shuffle):
     run, out = run_driver(tmp_path, algo, "ref_first", shuffle=shuffle, extra=("--ranks", str(ranks), "--sections", "4"))
     M, parts, Cs = merged(run, ranks, 165, 165)
     E = orc.read_mtx(f"{golden_dir}/ref_first/C_expected.mtx")
     orc.assert_same(to_o(M), E, rtol=0.0)
     assert parts == orc.partition_naive(165, 165, ranks)
+    if shuffle == "iterative":  # the permutations the driver saved are the oracle's (20 iterations by default)
+        rs, cs, _ = orc.iterative_shuffle(E, 20)
+        assert np.array_equal(np.loadtxt(run / "A_shuffle", dtype=np.int64), rs)
+        assert np.array_equal(np.loadtxt(run / "B_shuffle", dtype=np.int64), cs)
     if shuffle == "none" and ranks in (2, 4):
         want_nnz = {2: [782, 2285], 4: [182, 600, 759, 1526]}[ranks]      # recorded reference runs
         assert [c.nnz for c in Cs] == want_nnz

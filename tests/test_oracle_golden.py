@@ -119,3 +119,32 @@ def test_against_scipy_on_random_inputs():
         E.sort_indices()
         C = orc.spgemm(orc.OCsr.from_scipy(M), orc.OCsr.from_scipy(M))
         orc.assert_same(C, orc.OCsr.from_scipy(E), rtol=0.0)
+
+
+def test_iterative_shuffle_restated():
+    """The oracle's restatement of partition::iterative_shuffle (reference src/partition.cpp:123-202):
+    valid permutations, identity for zero iterations, a first row iteration that sorts the rows by
+    the mean of their column indices, and a shuffled band that is pulled back together."""
+    from spgemm_amd import hostcsr
+    from spgemm_amd import dist as sd
+    n = 1200
+    A = hostcsr.banded_random(n, 5, 20, seed=2)
+    perm = np.random.default_rng(0).permutation(n)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    S = sd.relabel_cols(sd.select_rows(A, perm), inv)
+    O = orc.OCsr(S.rows, S.cols, S.row_ptr, S.col_idx, S.val)
+    rs, cs, var = orc.iterative_shuffle(O, 0)
+    assert np.array_equal(rs, np.arange(n)) and np.array_equal(cs, np.arange(n)) and len(var) == 0
+    rs, cs, var = orc.iterative_shuffle(O, 1)
+    rp = O.row_ptr.astype(np.int64)
+    means = np.array([O.col_idx[rp[r]:rp[r + 1]].astype(np.float64).mean() if rp[r + 1] > rp[r] else n for r in range(n)])
+    assert np.array_equal(rs, np.argsort(means, kind="stable")) and np.array_equal(cs, np.arange(n))
+    rs, cs, var = orc.iterative_shuffle(O, 30)
+    assert np.array_equal(np.sort(rs), np.arange(n)) and np.array_equal(np.sort(cs), np.arange(n))
+    pos_r = np.empty(n, dtype=np.int64); pos_r[rs] = np.arange(n)
+    pos_c = np.empty(n, dtype=np.int64); pos_c[cs] = np.arange(n)
+    rid = np.repeat(np.arange(n), np.diff(rp))
+    after = np.abs(pos_r[rid] - pos_c[O.col_idx.astype(np.int64)]).mean()
+    before = np.abs(rid - O.col_idx.astype(np.int64)).mean()
+    assert after < 0.2 * before and var[-1] < var[0]
