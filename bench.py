@@ -36,6 +36,9 @@ def make_workload(args):
     if args.workload == "shell":
         A = hostcsr.shell_like()
         name = "af_shell10-like synthetic shell (n=1508065, ~35 nnz/row), C=A*A"
+    elif args.workload == "diel":
+        A = hostcsr.diel_like()
+        name = "dielFilterV3real-like synthetic 3-D grid (n=1104192, ~81 nnz/row), C=A*A"
     elif args.workload == "er":
         A = hostcsr.erdos_renyi(args.n, 16, seed=42)
         name = f"Erdos-Renyi n={args.n}, 16 draws/row, C=A*A"
@@ -173,7 +176,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="shell", choices=["shell", "er", "rmat", "mtx"])
+    ap.add_argument("--workload", default="shell", choices=["shell", "diel", "er", "rmat", "mtx"])
     ap.add_argument("--n", type=int, default=1 << 22, help="rows of the Erdos-Renyi workload")
     ap.add_argument("--scale", type=int, default=22, help="log2 rows of the R-MAT workload")
     ap.add_argument("--edge-factor", type=int, default=4)

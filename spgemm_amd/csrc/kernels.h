@@ -37,7 +37,11 @@ constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = NUM_HASH0 + 4 * HASH_TI
 constexpr int MAX_BINS = 192;
 static_assert(NUM_NBINS <= MAX_BINS && NUM_NBINS < 255, "bin keys are 8 bit");
 constexpr uint32_t GRP_MAX = 8;   // rows per group
-constexpr uint32_t GRP_ALEN = 64; // longest A row that is grouped (its values are staged in LDS)
+constexpr uint32_t GRP_ALEN = 64; // longest A row of such a group (the rows' values are staged in LDS)
+// "wide" groups: A rows of 65..GRP_ALEN_WIDE entries are grouped by GRP_MAX_WIDE at most (the same
+// LDS holds fewer, longer value lists)
+constexpr uint32_t GRP_MAX_WIDE = 4, GRP_ALEN_WIDE = 128;
+__host__ __device__ inline uint32_t group_max_rows(uint64_t len_a) { return len_a > GRP_ALEN ? GRP_MAX_WIDE : GRP_MAX; }
 
 struct ClassParams {
   uint32_t win_max_span;   // window path allowed up to this column span (<= 65536)
@@ -72,14 +76,17 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
   return SYM_GLOBAL0 + g;
 }
 
-__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t group_rows = 1) {
+// group bins: key = NUM_GRP0 + span_tier * 4 + q; q = 0: up to 128 outputs, q = 1: up to 512 (both:
+// up to GRP_MAX rows of up to GRP_ALEN entries), q = 2: up to 512 outputs, wide group
+__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t group_rows = 1,
+                                               bool wide = false) {
   if (nnz == 0) return KEY_NONE;
   uint32_t g = sym_key & 3u;
   if (sym_key < (uint32_t)SYM_HASH0) {
     uint32_t st = sym_key >> 2;
     if (nnz <= 8192u) {
       uint32_t ct = nnz <= 128 ? 0u : nnz <= 512 ? 1u : nnz <= 2048 ? 2u : 3u;
-      if (group_rows > 1 && ct <= 1) return NUM_GRP0 + st * 4 + ct;
+      if (group_rows > 1 && ct <= 1) return NUM_GRP0 + st * 4 + (wide ? 2u : ct);
       return NUM_WIN0 + (st * 4 + ct) * 4 + g;
     }
     return NUM_GLOBAL;
@@ -351,7 +358,7 @@ __global__ void __launch_bounds__(256)
   lead[i] = i;
   const uint32_t k = key[i];
   const uint64_t len = a_ptr[i + 1] - a_ptr[i];
-  if (!enable || k >= (uint32_t)SYM_HASH0 || len > GRP_ALEN) { // not a window row (or no products)
+  if (!enable || k >= (uint32_t)SYM_HASH0 || len > GRP_ALEN_WIDE) { // not a window row (or no products)
     gcnt[i] = 1;
     return;
   }
@@ -361,15 +368,16 @@ __global__ void __launch_bounds__(256)
     gcnt[i] = 1;
     return;
   }
-  if (pos % GRP_MAX != 0) { // follower: handled by its leader
+  const uint32_t gmax = group_max_rows(len); // the rows of a run have the same length
+  if (pos % gmax != 0) { // follower: handled by its leader
     gcnt[i] = 0;
     key[i] = (uint8_t)KEY_NONE;
     ub[i] = 0;
-    lead[i] = i - pos % GRP_MAX;
+    lead[i] = i - pos % gmax;
     return;
   }
   uint32_t c = 1;
-  while (c < GRP_MAX && i + c < rows && same[i + c]) ++c;
+  while (c < gmax && i + c < rows && same[i + c]) ++c;
   gcnt[i] = (uint8_t)c;
 }
 
@@ -887,7 +895,8 @@ __global__ void __launch_bounds__(256)
   const uint32_t cnt = m.gcnt[row];
   if (lane < cnt) {
     m.nnz[row + lane] = n;
-    const uint32_t gkey = num_key_of(m.sym_key[row], n, cnt);
+    const bool wide = A.ptr[row + 1] - A.ptr[row] > GRP_ALEN;
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, cnt, wide);
     const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
     m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n));
   }
@@ -1316,23 +1325,24 @@ __global__ void __launch_bounds__(256)
 // A that share their column list.  Every B entry is loaded once and its output position is found
 // once; it is then multiplied by each row's own A value (staged in LDS) and added to that row's
 // accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
-// LDS per wavefront: bmp[words] {bits, prefix} | vals[GRP_MAX][cap] | avals[GRP_MAX][GRP_ALEN].
+// LDS per wavefront: bmp[words] {bits, prefix} | vals[gmax][cap] | avals[gmax][alen], with
+// (gmax, alen) = (GRP_MAX, GRP_ALEN) or, for wide groups, (GRP_MAX_WIDE, GRP_ALEN_WIDE).
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-                     uint32_t words, uint32_t cap, uint32_t wpb) {
+                     uint32_t words, uint32_t cap, uint32_t wpb, uint32_t gmax, uint32_t alen) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (w >= wpb || idx >= nrows) return;
-  const size_t region = (size_t)words * 8u + (size_t)GRP_MAX * cap * 8u + (size_t)GRP_MAX * GRP_ALEN * 8u;
+  const size_t region = (size_t)words * 8u + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
   uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
   uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
   double *vals = reinterpret_cast<double *>(bmp + words);
-  double *avals = vals + (size_t)GRP_MAX * cap;
+  double *avals = vals + (size_t)gmax * cap;
   // row state through the scalar unit (all of it was written by earlier kernels)
   const uint32_t row = scalar_view(rows)[idx];
-  const uint32_t cnt = min((uint32_t)scalar_view(m.gcnt)[row], GRP_MAX);
+  const uint32_t cnt = min((uint32_t)scalar_view(m.gcnt)[row], gmax);
   const uint32_t base = scalar_view(m.cmin)[row] & ~31u;
   const uint32_t nw = ((scalar_view(m.cmax)[row] - base) >> 5) + 1u;
   const uint32_t n = scalar_view((const uint32_t *)m.nnz)[row];
@@ -1353,7 +1363,7 @@ __global__ void __launch_bounds__(256)
     if (j < cnt) {
       for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
       const double *av = A.val + readlane64(my_a, j);
-      for (uint32_t t = lane; t < len_a && t < GRP_ALEN; t += 64) avals[j * GRP_ALEN + t] = av[t];
+      for (uint32_t t = lane; t < len_a && t < alen; t += 64) avals[j * alen + t] = av[t];
     }
   }
   lds_fence();
@@ -1379,7 +1389,7 @@ __global__ void __launch_bounds__(256)
     uint32_t cc = c - base;
     uint64_t e = bmp[cc >> 5];
     uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
-    for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * GRP_ALEN + apos], bv));
+    for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * alen + apos], bv));
   });
   lds_fence();
   uint32_t nz = 0;

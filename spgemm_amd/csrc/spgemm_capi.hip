@@ -833,14 +833,16 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
     uint32_t cnt = (uint32_t)cnt64;
     const uint32_t *rows_bin = perm + boff[key];
     if (key >= NUM_GRP0) {
-      uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, ct = (uint32_t)(key - NUM_GRP0) & 3;
-      uint32_t words = (64u << st_) + 2u, cap = 128u << (2 * ct);
-      size_t region = (size_t)words * 8 + (size_t)GRP_MAX * cap * 8 + (size_t)GRP_MAX * GRP_ALEN * 8;
+      uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, q = (uint32_t)(key - NUM_GRP0) & 3;
+      const bool wide = q == 2;
+      uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : 512u;
+      const uint32_t gmax = wide ? GRP_MAX_WIDE : GRP_MAX, alen = wide ? GRP_ALEN_WIDE : GRP_ALEN;
+      size_t region = (size_t)words * 8 + (size_t)gmax * cap * 8 + (size_t)gmax * alen * 8;
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
       hipLaunchKernelGGL(k_num_window_grp, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
-                         cnt, cA, cB, rm, no, words, cap, wpb);
+                         cnt, cA, cB, rm, no, words, cap, wpb, gmax, alen);
     } else if (key < NUM_GLOBAL) {
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       const bool window = key < NUM_HASH0;

@@ -164,6 +164,14 @@ def shell_like(n_nodes: int = 301_613, grid_w: int = 549, dofs: int = 5, seed: i
         q = qy * W + qx
         ok = (qx >= 0) & (qx < W) & (qy >= 0) & (q < N)
         nb[ok, t] = q[ok]
+    return _fem_matrix(nb, dofs, seed)
+
+
+def _fem_matrix(nb: np.ndarray, dofs: int, seed: int) -> HostCsr:
+    """nb[p, t] = t-th neighbour of node p (ascending node index, -1 where there is none, the node
+    itself included): every node pair is coupled by a dense dofs x dofs block; values uniform in
+    [-1, 1) with a dominant diagonal; rows sorted by column."""
+    N = nb.shape[0]
     valid = nb >= 0
     cnt = valid.sum(axis=1)                                  # neighbours per node
     row_len_node = cnt * dofs
@@ -191,6 +199,23 @@ def shell_like(n_nodes: int = 301_613, grid_w: int = 549, dofs: int = 5, seed: i
     rows_of = np.repeat(np.arange(n, dtype=np.int64), lens)
     val[col_idx == rows_of] += 10.0
     return HostCsr(n, n, row_ptr, col_idx, val)
+
+
+def diel_like(nx: int = 71, ny: int = 72, nz: int = 72, dofs: int = 3, seed: int = 11) -> HostCsr:
+    """Stand-in for SuiteSparse Dziekonski/dielFilterV3real (not downloadable here): about the same
+    order (1,102,824; here 3 * 71 * 72 * 72 = 1,104,192) and entries per row (~81).  Nodes of a
+    structured 3-D grid, `dofs` unknowns per node, every node coupled to the 27 nodes of its
+    3 x 3 x 3 neighbourhood by dense dofs x dofs blocks."""
+    N = nx * ny * nz
+    p = np.arange(N, dtype=np.int64)
+    x, y, z = p % nx, (p // nx) % ny, p // (nx * ny)
+    offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]  # ascending node index
+    nb = np.full((N, len(offs)), -1, dtype=np.int64)
+    for t, (dx, dy, dz) in enumerate(offs):
+        qx, qy, qz = x + dx, y + dy, z + dz
+        ok = (qx >= 0) & (qx < nx) & (qy >= 0) & (qy < ny) & (qz >= 0) & (qz < nz)
+        nb[ok, t] = (qx + nx * (qy + ny * qz))[ok]
+    return _fem_matrix(nb, dofs, seed)
 
 
 def banded_random(n: int, per_row: int, half_band: int, seed: int = 3, signed: bool = True) -> HostCsr:

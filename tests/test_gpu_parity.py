@@ -111,6 +111,13 @@ def test_shell_like_small(ctx):
     assert st["rows_window"] in (A.rows, A.rows // 5)  # symbolic runs once per group of identical rows
 
 
+def test_diel_like_small(ctx):
+    """3-D grid stand-in of dielFilterV3real: 27-point neighbourhoods, 3 unknowns per node."""
+    A = hostcsr.diel_like(9, 8, 7)
+    _, st = check(ctx, A, A)
+    assert st["rows_window"] > 0
+
+
 def test_exact_cancellation_is_dropped(ctx):
     # row 0 of A*B: column 0 gets 1*1 + 1*(-1) = 0 exactly -> erased; column 1 survives.
     A = hostcsr.HostCsr.from_coo(3, 2, [0, 0, 1, 2], [0, 1, 0, 1], [1.0, 1.0, 2.0, 3.0])
@@ -189,7 +196,7 @@ def test_section_bitmap_matches_oracle(ctx, golden_dir):
     d.free()
 
 
-@pytest.mark.parametrize("dofs", [2, 5, 8, 13, 70])
+@pytest.mark.parametrize("dofs", [2, 5, 8, 13, 20, 30, 70])
 def test_row_groups_identical_patterns(ctx, dofs):
     # every node has `dofs` unknowns whose rows share one column list: runs of identical rows of
     # length dofs (shorter, equal and longer than a group, and longer than the run limit)
