@@ -97,6 +97,8 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   big_win_words                                   bitmap window of the big-row symbolic kernel
  *                                                   (32-column words, multiple of 1024, <= 32768)
  *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)
+ *   hash_num_slice                                  LDS-hash rows with more outputs than this are
+ *                                                   accumulated by the big-row numeric kernel
  *   global_blocks_sym, global_blocks_num            workgroups of the unsorted-B fallback kernels
  *   profile_launches                                0 off, 1 HIP events per launch, 2 + per-launch sums */
 int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value);

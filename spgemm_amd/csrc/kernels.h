@@ -78,8 +78,10 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
 
 // group bins: key = NUM_GRP0 + span_tier * 4 + q; q = 0: up to 128 outputs, q = 1: up to 512 (both:
 // up to GRP_MAX rows of up to GRP_ALEN entries), q = 2: up to 512 outputs, wide group
-__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t group_rows = 1,
-                                               bool wide = false) {
+// hash_num_max: most outputs of a row that is accumulated by the LDS hash kernel (<= 4096); rows
+// beyond it go to the big-row bin
+__host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t hash_num_max,
+                                               uint32_t group_rows = 1, bool wide = false) {
   if (nnz == 0) return KEY_NONE;
   uint32_t g = sym_key & 3u;
   if (sym_key < (uint32_t)SYM_HASH0) {
@@ -91,7 +93,7 @@ __host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, u
     }
     return NUM_GLOBAL;
   }
-  if (nnz <= 4096u) {
+  if (nnz <= hash_num_max) {
     uint32_t ct = ceil_log2_u32(nnz < 64u ? 64u : nnz) - 6u; // nnz <= 64 << ct
     return NUM_HASH0 + ct * 4 + g;
   }
@@ -561,6 +563,7 @@ struct RowMeta {
   uint8_t *__restrict__ num_key;      // numeric bin key per row
   const uint8_t *__restrict__ gcnt;   // rows in the group led by this row (0: follower)
   const uint32_t *__restrict__ lead;  // leader of the row's group (the row itself when ungrouped)
+  uint32_t hash_num_max;              // see num_key_of
 };
 
 // ---- walking the products of one row ----------------------------------------------------------
@@ -896,9 +899,9 @@ __global__ void __launch_bounds__(256)
   if (lane < cnt) {
     m.nnz[row + lane] = n;
     const bool wide = A.ptr[row + 1] - A.ptr[row] > GRP_ALEN;
-    const uint32_t gkey = num_key_of(m.sym_key[row], n, cnt, wide);
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, wide);
     const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
-    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n));
+    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
   }
 }
 
@@ -982,7 +985,92 @@ __global__ void __launch_bounds__(256)
   }
   if (lane == 0) {
     m.nnz[row] = n;
-    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
+  }
+}
+
+// ---- symbolic, hash path, large tables: one 256-thread workgroup per row ---------------------------
+// The same algorithm as k_sym_hash with the four wavefronts of a workgroup sharing one table (the
+// pattern of a row does not depend on the order in which its products are seen): a table of 8192
+// slots takes 64 KiB of LDS, and one wavefront per table would leave two wavefronts on a CU.
+// The wavefronts take the A entries round robin.  LDS: keys[S] | cnt[S/2] | tk[S/2] = 8*S bytes.
+__global__ void __launch_bounds__(256)
+    k_sym_hash_wg(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_n, s_wsum[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *cnt = keys + S;
+  uint32_t *tk = cnt + NB;
+  const uint32_t row = scalar_view(rows)[xcd_remap(blockIdx.x, gridDim.x)];
+  for (uint32_t i = tid; i < S; i += 256) keys[i] = EMPTY_KEY;
+  for (uint32_t i = tid; i < NB; i += 256) cnt[i] = 0u;
+  if (tid == 0) s_n = 0u;
+  __syncthreads();
+  const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
+  uint32_t mine = 0;
+  for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
+    const uint32_t k = scalar_view(A.col)[ka];
+    const uint64_t b0 = scalar_view(B.ptr)[k], b1 = scalar_view(B.ptr)[k + 1];
+    for (uint64_t j = b0 + lane; j < b1; j += 64) {
+      const uint32_t c = B.col[j];
+      uint32_t h = hash_slot(c, log2s);
+      for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+        const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+        if (old == EMPTY_KEY) { ++mine; break; }
+        if (old == c) break;
+        h = (h + 1u) & mask;
+      }
+    }
+  }
+  mine = group_last<64>(group_incl_scan<64>(mine));
+  if (lane == 0 && mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  const uint32_t n = s_n;
+  const uint32_t cmin = m.cmin[row];
+  const float scale = (float)NB / (float)(m.cmax[row] - cmin + 1u);
+  // pass A: bucket counts (buckets are monotone in the column)
+  for (uint32_t s = tid; s < S; s += 256) {
+    const uint32_t key = keys[s];
+    if (key != EMPTY_KEY) atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of cnt: NB / 256 consecutive buckets per thread (NB is a multiple of 256 here)
+  const uint32_t per = NB >> 8;
+  uint32_t local = 0;
+  for (uint32_t i = 0; i < per; ++i) local += cnt[tid * per + i];
+  const uint32_t incl = group_incl_scan<64>(local);
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  uint32_t run = incl - local;
+  for (uint32_t i = 0; i < w; ++i) run += s_wsum[i];
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t v = cnt[tid * per + i];
+    cnt[tid * per + i] = run;
+    run += v;
+  }
+  __syncthreads();
+  // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
+  for (uint32_t s = tid; s < S; s += 256) {
+    const uint32_t key = keys[s];
+    if (key != EMPTY_KEY) tk[atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u)] = key;
+  }
+  __syncthreads();
+  // pass C: rank inside the bucket, write sorted
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = tid; p < n; p += 256) {
+    const uint32_t key = tk[p];
+    const uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+    const uint32_t start = b ? cnt[b - 1] : 0u, end = cnt[b];
+    uint32_t rank = start;
+    for (uint32_t q = start; q < end; ++q) rank += (tk[q] < key) ? 1u : 0u;
+    out[rank] = key;
+  }
+  if (tid == 0) {
+    m.nnz[row] = n;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
   }
 }
 
@@ -1031,7 +1119,7 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) {
       uint32_t n = s_carry;
       m.nnz[row] = n;
-      m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n);
+      m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
     }
     __syncthreads();
   }
@@ -1234,7 +1322,7 @@ __global__ void __launch_bounds__(BIG_THREADS)
   }
   if (tid == 0) {
     m.nnz[row] = carry;
-    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry);
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry, m.hash_num_max);
   }
 }
 

@@ -88,6 +88,7 @@ struct spgemm_ctx {
   uint32_t big_rows = 1;         // big rows of a sorted B: LDS bitmap windows / output slices
   uint32_t slice_blocks = 0;     // workgroups of the slice kernel (0: fill the device)
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
+  uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
@@ -268,6 +269,7 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
   raise_lds_limit(k_sym_big);
+  raise_lds_limit(k_sym_hash_wg);
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -426,6 +428,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     if (value < (int64_t)BIG_THREADS || value > 32768 || value % BIG_THREADS)
       return fail(SPGEMM_ERR_INVALID, "big_win_words must be a multiple of 1024 in 1024..32768");
     ctx->big_win_words = (uint32_t)value;
+  } else if (n == "hash_num_slice") {
+    if (value < 64 || value > 4096) return fail(SPGEMM_ERR_INVALID, "hash_num_slice must be 64..4096");
+    ctx->hash_num_slice = (uint32_t)value;
   } else if (n == "slice_blocks") {
     if (value < 0 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_blocks must be 0..65536");
     ctx->slice_blocks = (uint32_t)value;
@@ -716,7 +721,11 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
-  RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey, r_gcnt, r_lead};
+  // with the big-row kernels available, rows of more than hash_num_slice outputs leave the LDS hash
+  // kernel (whose largest tables leave room for two wavefronts per CU) for the slice kernel
+  const uint32_t hash_num_max = (b_sorted && ctx->big_rows) ? ctx->hash_num_slice : 4096u;
+  RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey, r_gcnt, r_lead,
+             hash_num_max};
 
   for (int key = 0; key < SYM_NBINS; ++key) {
     uint64_t cnt64 = boff[key + 1] - boff[key];
@@ -740,6 +749,14 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
       st.rows_hash += cnt;
+      if (!flat && log2s >= 12) { // 32 KiB of table and more: the four wavefronts of a workgroup share it
+        TRY(prof_begin(ctx, 0, 1, 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
+        hipLaunchKernelGGL(k_sym_hash_wg, dim3(cnt), dim3(256), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB, rm,
+                           log2s);
+        HIP_TRY(hipGetLastError());
+        TRY(prof_end(ctx));
+        continue;
+      }
       TRY(prof_begin(ctx, 0, 1, flat ? 0 : 64, cnt, log2s, 0, region * wpb, rows_bin));
       hipLaunchKernelGGL(flat ? k_sym_hash<true> : k_sym_hash<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
@@ -823,7 +840,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
   RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
-             pl.r_numkey, pl.r_gcnt, pl.r_lead};
+             pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u};
   NumOut no{d_row_ptr, d_col, d_val, zero_count};
   const size_t lds_max = 160 * 1024;
 
