@@ -1,0 +1,91 @@
+"""Randomised GPU parity sweep: small matrices of varied structure, multiplied under randomly chosen
+row-binning options so that every kernel family (window, row groups, LDS hash, workgroup hash,
+big-row windows and slices, unsorted-B fallback) sees them; each result is compared bit for bit
+with the CPU oracle.  Seeds are fixed: a failure names its case."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from spgemm_amd import capi, hostcsr
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = {"window_max_span": 65536, "window_ratio": 128, "hash_max_nprod": 4096, "big_win_words": 32768,
+            "slice_blocks": 0, "hash_num_slice": 1024, "row_groups": 1, "flat_walk": 1, "big_rows": 1,
+            "g_thresh2": 24}
+
+
+def to_o(h):
+    return orc.OCsr(h.rows, h.cols, h.row_ptr, h.col_idx, h.val)
+
+
+def random_matrix(rng, rows, cols):
+    kind = rng.integers(0, 5)
+    if kind == 0:      # uniform random
+        nnz = int(rng.integers(1, 12) * rows)
+        r, c = rng.integers(0, rows, nnz), rng.integers(0, cols, nnz)
+    elif kind == 1:    # skewed: a few hub rows and hub columns
+        nnz = int(rng.integers(2, 10) * rows)
+        r = (rows * rng.random(nnz) ** 3).astype(np.int64)
+        c = (cols * rng.random(nnz) ** 3).astype(np.int64)
+    elif kind == 2:    # banded
+        nnz = int(rng.integers(2, 9) * rows)
+        r = rng.integers(0, rows, nnz)
+        c = np.clip((r * cols) // rows + rng.integers(-20, 21, nnz), 0, cols - 1)
+    elif kind == 3:    # blocks of identical rows (row groups), some long rows
+        d = int(rng.integers(2, 7))
+        base = rng.integers(0, cols, (max(rows // d, 1), int(rng.integers(2, 30))))
+        r = np.repeat(np.arange(base.shape[0] * d), base.shape[1]) % rows
+        c = np.repeat(base, d, axis=0).ravel()
+    else:              # one dense-ish row and column on top of a sparse background
+        nnz = int(3 * rows)
+        r, c = rng.integers(0, rows, nnz), rng.integers(0, cols, nnz)
+        hub = int(rng.integers(0, rows))
+        r = np.concatenate([r, np.full(cols // 2, hub)])
+        c = np.concatenate([c, rng.choice(cols, cols // 2, replace=False)])
+    v = rng.integers(-3, 4, len(r)).astype(np.float64)  # small integers: exact cancellations do happen
+    v[v == 0] = 0.5
+    M = hostcsr.HostCsr.from_coo(rows, cols, r, c, v, sum_duplicates=True).sorted_rows()
+    keep = M.val != 0.0  # duplicates that summed to 0.0 do not stay as explicit zeros
+    return hostcsr.HostCsr.from_coo(rows, cols, M.row_ids()[keep], M.col_idx[keep].astype(np.int64), M.val[keep]).sorted_rows()
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_structure_and_options(seed):
+    rng = np.random.default_rng(1000 + seed)
+    m, k, n = (int(x) for x in rng.integers(40, 2500, 3))
+    if seed % 3 == 0:
+        m = k = n = int(rng.integers(300, 3000))
+    A, B = random_matrix(rng, m, k), random_matrix(rng, k, n)
+    # an entry whose sum of duplicates is 0.0 must not reach the operands as an explicit zero
+    for M in (A, B):
+        assert np.all(M.val != 0.0)
+    opts = dict(DEFAULTS)
+    opts["window_max_span"] = int(rng.choice([0, 512, 65536]))
+    opts["hash_max_nprod"] = int(rng.choice([0, 64, 512, 4096]))
+    opts["big_win_words"] = int(rng.choice([1024, 32768]))
+    opts["slice_blocks"] = int(rng.choice([0, 1, 7]))
+    opts["hash_num_slice"] = int(rng.choice([64, 1024, 4096]))
+    opts["row_groups"] = int(rng.integers(0, 2))
+    opts["flat_walk"] = int(rng.integers(0, 2))
+    opts["big_rows"] = int(rng.integers(0, 4) != 0)
+    opts["g_thresh2"] = int(rng.choice([24, 100000]))
+    unsorted_b = seed % 5 == 4
+    if unsorted_b:  # rows of B in reverse column order: the general (unsorted) path
+        rp = B.row_ptr.astype(np.int64)
+        order = np.concatenate([np.arange(rp[i + 1] - 1, rp[i] - 1, -1) for i in range(B.rows)]) if B.nnz else np.zeros(0, np.int64)
+        B = hostcsr.HostCsr(B.rows, B.cols, B.row_ptr, B.col_idx[order], B.val[order])
+    ctx = capi.Context(0)
+    try:
+        for name, value in opts.items():
+            ctx.set_option(name, value)
+        dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+        dB = ctx.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
+        for _ in range(2):  # the second multiply reuses the context's scratch
+            dC = ctx.multiply(dA, dB)
+            rp, ci, v = dC.to_host()
+            dC.free()
+            E = orc.spgemm(to_o(A), to_o(B))
+            orc.assert_same(orc.OCsr(A.rows, B.cols, rp, ci, v), E, rtol=0.0)
+    finally:
+        ctx.close()
