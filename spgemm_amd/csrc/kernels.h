@@ -1580,6 +1580,9 @@ __global__ void __launch_bounds__(256)
 // ({position in B, end position, A value, next column}, in A order; global scratch, `list_cap`
 // entries per workgroup).  A chunk then looks only at the list's `next column` to find the entries
 // it has to touch, and advances their positions for the chunk that follows.
+#ifndef SG_SLICE_UG
+#define SG_SLICE_UG 4
+#endif
 constexpr uint32_t SLICE_W = 1024;
 constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES; // cols u32 | vals f64 | owner u32 | flat-walk scratch
 
@@ -1688,7 +1691,8 @@ __global__ void __launch_bounds__(64)
   for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
   uint32_t stamp = 0;
   uint32_t nz = 0;
-  constexpr int U = 4; // B row pieces whose loads and column searches are in flight together
+  constexpr int U = 4;  // blocks of list entries whose loads and searches are in flight together
+  constexpr int UG = SG_SLICE_UG; // B row pieces whose loads and column searches are in flight together
 #ifdef SG_SLICE_STAMPS
   // diagnostic build: cycles per phase, summed over the wavefronts into o.zero_count[8..]
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1797,11 +1801,15 @@ __global__ void __launch_bounds__(64)
       }
       lds_fence();
       SG_STAMP(2)
-      auto find = [&](uint32_t col) { // position of a column that is in the chunk
+      // position of a column that is in the chunk: four-way search, three probes per level in
+      // flight together (five dependent LDS round trips instead of ten)
+      auto find = [&](uint32_t col) {
         uint32_t pos = 0;
 #pragma unroll
-        for (uint32_t s = SLICE_W / 2; s > 0; s >>= 1)
-          if (scol[pos + s] <= col) pos += s;
+        for (uint32_t len = SLICE_W / 4; len > 0; len >>= 2) {
+          const uint32_t a = scol[pos + len], b = scol[pos + 2u * len], c = scol[pos + 3u * len];
+          pos += len * ((a <= col ? 1u : 0u) + (b <= col ? 1u : 0u) + (c <= col ? 1u : 0u));
+        }
         return pos;
       };
       // One block of up to 64 list entries (one per lane; `act` = has entries in this chunk): adds
@@ -1815,17 +1823,17 @@ __global__ void __launch_bounds__(64)
         if (group_sum<64>(est) >= 16u * nact) {
           // long pieces: one B row at a time, its entries over the lanes (distinct columns: no
           // conflicts); U pieces are loaded and searched together, then added in A order
-          // group = U pieces; the loads of the next group fly while this one is searched and added
+          // group = UG pieces; the loads of the next group fly while this one is searched and added
           struct Group {
-            uint32_t l[U], rem[U], col[U];
-            uint64_t p0[U], pend[U];
-            double a[U], v[U];
-            bool on[U];
+            uint32_t l[UG], rem[UG], col[UG];
+            uint64_t p0[UG], pend[UG];
+            double a[UG], v[UG];
+            bool on[UG];
           };
           uint64_t mask = amask;
           auto fetch = [&](Group &g) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UG; ++u) {
               g.on[u] = mask != 0;
               g.l[u] = g.on[u] ? (uint32_t)__builtin_ctzll(mask) : 0u;
               if (g.on[u]) mask &= mask - 1ull;
@@ -1835,7 +1843,7 @@ __global__ void __launch_bounds__(64)
               g.rem[u] = g.on[u] ? (uint32_t)min(g.pend[u] - g.p0[u], (uint64_t)64) : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UG; ++u) {
               const bool have = lane < g.rem[u];
               g.col[u] = have ? B.col[g.p0[u] + lane] : EMPTY_KEY;
               g.v[u] = have ? B.val[g.p0[u] + lane] : 0.0;
@@ -1846,15 +1854,15 @@ __global__ void __launch_bounds__(64)
           while (g.on[0]) {
             gn.on[0] = false;
             if (mask) fetch(gn); // other lanes' pieces: not touched by what follows
-            uint32_t pos[U];
-            bool in[U];
+            uint32_t pos[UG];
+            bool in[UG];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UG; ++u) {
               in[u] = lane < g.rem[u] && (uint64_t)g.col[u] < chi;
               pos[u] = find(in[u] ? g.col[u] : 0u);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UG; ++u) {
               if (!g.on[u]) continue; // wave-uniform
               if (in[u]) lds_add_f64(&vals[pos[u]], __dmul_rn(g.a[u], g.v[u]));
               uint32_t took = (uint32_t)__popcll(__ballot(in[u]));
