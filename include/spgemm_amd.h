@@ -144,8 +144,10 @@ int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out);
  * measure points are per phase (include/measure.hpp:16-30). */
 typedef struct spgemm_launch_info {
   uint32_t phase;  /* 0 symbolic, 1 numeric */
-  uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch, 3 window for row groups */
-  uint32_t lanes;  /* 64: one A entry per wavefront step; 0: flat walk (products laid end to end) */
+  uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch, 3 window for row groups,
+                      4 big rows (symbolic: bitmap windows per workgroup; numeric: output slices) */
+  uint32_t lanes;  /* 64: one A entry per wavefront step; 0: flat walk (products laid end to end);
+                      256 / 1024: threads of the workgroup that shares one row */
   uint32_t rows;   /* rows handled by the launch */
   uint32_t param0; /* window: bitmap words; hash: log2 of the table size */
   uint32_t param1; /* window numeric: value slots */

@@ -766,7 +766,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       size_t lds = sym_big_lds(win_words);
       if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 16));
       st.rows_global += cnt;
-      TRY(prof_begin(ctx, 0, 2, 64, cnt, win_words, 0, lds, rows_bin));
+      TRY(prof_begin(ctx, 0, 4, BIG_THREADS, cnt, win_words, 0, lds, rows_bin));
       hipLaunchKernelGGL(k_sym_big, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, win_words,
                          reinterpret_cast<uint64_t *>(ctx->big_cur.p), A->nnz);
     } else {
@@ -900,7 +900,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       uint64_t *s_off = reinterpret_cast<uint64_t *>(sb + b_count);
       SliceItem *s_items = reinterpret_cast<SliceItem *>(sb + b_count + b_off);
       unsigned char *s_lists = reinterpret_cast<unsigned char *>(sb + b_count + b_off + b_items);
-      TRY(prof_begin(ctx, 1, 2, 64, cnt, SLICE_W, blocks, SLICE_LDS, rows_bin));
+      TRY(prof_begin(ctx, 1, 4, 64, cnt, SLICE_W, blocks, SLICE_LDS, rows_bin));
       hipLaunchKernelGGL(k_slice_count, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
                          pl.r_nnz, s_count);
       TRY(launch_scan(ctx, s_count, cnt, s_off, partial));
