@@ -1415,9 +1415,11 @@ __global__ void __launch_bounds__(256)
 // accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
 // LDS per wavefront: bmp[words] {bits, prefix} | vals[gmax][cap] | avals[gmax][alen], with
 // (gmax, alen) = (GRP_MAX, GRP_ALEN) or, for wide groups, (GRP_MAX_WIDE, GRP_ALEN_WIDE).
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-                     uint32_t words, uint32_t cap, uint32_t wpb, uint32_t gmax, uint32_t alen) {
+                     uint32_t words, uint32_t cap, uint32_t wpb) {
+  constexpr uint32_t gmax = WIDE ? GRP_MAX_WIDE : GRP_MAX, alen = WIDE ? GRP_ALEN_WIDE : GRP_ALEN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -264,7 +264,7 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
-  raise_lds_limit(k_num_window_grp);
+  raise_lds_limit(k_num_window_grp<true>); raise_lds_limit(k_num_window_grp<false>);
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
@@ -858,8 +858,8 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
-      hipLaunchKernelGGL(k_num_window_grp, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin,
-                         cnt, cA, cB, rm, no, words, cap, wpb, gmax, alen);
+      hipLaunchKernelGGL(wide ? k_num_window_grp<true> : k_num_window_grp<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
+                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb);
     } else if (key < NUM_GLOBAL) {
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       const bool window = key < NUM_HASH0;
