@@ -580,12 +580,6 @@ __device__ __forceinline__ double readlane_f64(double v, uint32_t l) {
 #ifndef SG_PF
 #define SG_PF 4
 #endif
-#ifndef SG_SYM_COMBINE
-#define SG_SYM_COMBINE 1
-#endif
-#ifndef SG_SYM_ENUM_SEARCH
-#define SG_SYM_ENUM_SEARCH 1
-#endif
 constexpr int PF = SG_PF; // B rows whose first 64 entries are fetched before any of them is consumed
 
 // Wave-per-row walk with the A row handled on the scalar unit.  `row` must be wave-uniform
@@ -822,10 +816,10 @@ __device__ __forceinline__ uint32_t select_bit(uint32_t bits, uint32_t r) {
 // LDS per wavefront: `words` pairs {bitmap word, number of set bits before it} covering columns
 // [cmin & ~31, cmax].
 //
-// B rows are runs of neighbouring columns, so many lanes of one instruction would OR into the
-// same bitmap word and the LDS would serialise them.  Lanes first combine their bits inside
-// each 16-lane row (an OR-scan over lanes that share the word), and only the last lane of every
-// run issues the LDS atomic.
+// Every product ORs its bit into the bitmap (lanes of one instruction that share a word are
+// serialised by the LDS; combining them first in registers was measured and cost more than it
+// saved).  The sorted column list is then written coalesced: output position p finds the word
+// that holds the p-th set bit by a binary search over the per-word prefix counts.
 // FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
 template <bool FLAT>
 __global__ void __launch_bounds__(256)
@@ -851,25 +845,6 @@ __global__ void __launch_bounds__(256)
   if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)words * 8u, mark);
   else wave_row_walk<false>(A, B, row, lane, mark);
   lds_fence();
-#if !SG_SYM_ENUM_SEARCH
-  uint32_t *out = m.temp_cols + m.t_off[row];
-  uint32_t carry = 0;
-  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
-    uint32_t wi = r0 + lane;
-    uint32_t bits = wi < nw ? bm[wi * 2u] : 0u;
-    uint32_t pc = __popc(bits);
-    uint32_t incl = group_incl_scan<64>(pc);
-    uint32_t pos = carry + incl - pc;
-    uint32_t cbase = base + (wi << 5);
-    while (bits) {
-      uint32_t b = __ffs(bits) - 1;
-      out[pos++] = cbase + b;
-      bits &= bits - 1u;
-    }
-    carry += group_last<64>(incl);
-  }
-  const uint32_t n = carry;
-#else
   // per-word prefix of the set-bit counts
   uint32_t carry = 0;
   for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
@@ -892,7 +867,6 @@ __global__ void __launch_bounds__(256)
     uint2 e = *reinterpret_cast<const uint2 *>(&bm[lo * 2u]);
     out[p] = base + (lo << 5) + select_bit(e.x, p - e.y);
   }
-#endif
   // the group's rows share the pattern: same nnz; they are accumulated together when the group
   // kernel has a tier for them, else one by one (each reading the leader's column list)
   const uint32_t cnt = m.gcnt[row];
