@@ -1114,6 +1114,7 @@ __global__ void __launch_bounds__(256)
 // LDS: win_words u32 bitmap | BIG_CUR u64 pos | BIG_CUR u64 end | BIG_CUR u32 list of mid pieces |
 //      BIG_CUR u32 list of long pieces | BIG_CUR u32 entries taken from long pieces | win_words / 64 u32 (block offsets; a quarter used).
 constexpr uint32_t BIG_THREADS = 1024, BIG_WAVES = 16, BIG_CUR = 1024, BIG_MID = 256;
+static_assert(BIG_CUR == BIG_THREADS, "a batch of A entries is one entry per thread, and the piece lists hold one batch");
 constexpr uint32_t BIG_WIN_MAX = 32768;                   // words of the largest window
 constexpr uint32_t BIG_BPW = BIG_WIN_MAX / 256 / BIG_WAVES; // blocks of 256 words per wavefront and window
 __host__ __device__ inline size_t sym_big_lds(uint32_t win_words) {
