@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--impl", default="drop", choices=["baseline", "drop", "shuffle"],
                     help="distributed variant (N > 1): all sections, bitmap-filtered sections, "
                          "or random row/column shuffle + bitmap")
+    ap.add_argument("--partition", default="naive", choices=["naive", "balanced"],
+                    help="row blocks of the distributed variant: equal row counts, or equal product counts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (spgemm_set_option), e.g. --opt row_groups=0")

@@ -57,6 +57,14 @@ def make_shuffles(n_rows: int, n_cols: int, impl: str, seed: int) -> Tuple[np.nd
     return np.arange(n_rows, dtype=np.int64), np.arange(n_cols, dtype=np.int64)
 
 
+def row_products(A: HostCsr, B: HostCsr) -> np.ndarray:
+    """Products per row of A * B: the sum of the lengths of the B rows its entries select."""
+    len_b = np.diff(B.row_ptr.astype(np.int64))
+    w = np.zeros(A.rows, dtype=np.int64)
+    np.add.at(w, A.row_ids(), len_b[A.col_idx.astype(np.int64)])
+    return w.astype(np.uint64)
+
+
 def iterative_shuffles(ctx, A: HostCsr, B: HostCsr, iterations: int = 20) -> Tuple[np.ndarray, np.ndarray]:
     """The reference's `iterative` shuffling (src/main.cpp:151-152, src/partition.cpp:123-202): the
     pattern of C is computed here on the device (the reference reads C_sparsity.mtx)."""
@@ -319,8 +327,13 @@ class DistSpgemm:
             self.A_shuffle, self.B_shuffle = make_shuffles(A.rows, B.cols, kind, seed)
         if partition == "naive":
             self.partitions = capi.partition_naive(A.rows, B.cols, self.world)
+        elif partition == "balanced":
+            # reference src/parts/baseline.cpp:44-86 cuts the (shuffled) rows by their share of
+            # nnz(C_sparsity); here the weight of a row is its number of products, which needs no
+            # pattern of the answer
+            self.partitions = capi.partition_balanced(row_products(A, B)[self.A_shuffle], B.cols, self.world)
         else:
-            raise ValueError("only the naive partition is wired into DistSpgemm")
+            raise ValueError("partition must be naive or balanced")
         self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
                                        n_sections)
         ap = self.ops.A_part
@@ -402,7 +415,8 @@ def bench_main(args):
     else:
         dist.init_process_group(backend)
     A, name = bench_mod.make_workload(args)
-    op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local)
+    op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local,
+                    partition=getattr(args, "partition", "naive"))
     op.ctx.set_option("profile_launches", 1)  # HIP events around every launch, on the operator's stream
     for o in getattr(args, "opt", []):
         opt_name, opt_value = o.split("=")
@@ -463,7 +477,7 @@ def bench_main(args):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if args.workload != "mtx" else "file",
             "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": int(nprod), "nnz_c": int(nnz_c),
-                       "impl": args.impl, "n_sections": 512,
+                       "impl": args.impl, "n_sections": 512, "partition": getattr(args, "partition", "naive"),
                        "parallelism": f"{world} GPUs, A by row blocks, B row sections by all-to-all (RCCL)"},
             "exchange": {"bytes_sent_all_ranks_per_step": int(sent), "b_entries_resident_all_ranks": int(nnz_b_local),
                          "mean_section_drop_fraction": float(drop.item()) / world},

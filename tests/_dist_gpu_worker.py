@@ -32,8 +32,10 @@ def main():
     for name, A, N in cases:
         E = orc.spgemm(to_o(A), to_o(A))
         sent = {}
-        for impl in ("baseline", "drop", "shuffle"):
-            op = sd.DistSpgemm(A, None, impl=impl, n_sections=N, seed=7, device_index=0)
+        for impl in ("baseline", "drop", "shuffle", "drop+balanced"):
+            partition = "balanced" if impl.endswith("+balanced") else "naive"
+            impl = impl.split("+")[0]
+            op = sd.DistSpgemm(A, None, impl=impl, n_sections=N, seed=7, device_index=0, partition=partition)
             op.gemm()
             op.gemm()
             C = op.result()
@@ -51,7 +53,7 @@ def main():
                 orc.assert_same(to_o(M), E, rtol=0.0)
             tot = torch.tensor([op.exchange.bytes_sent_per_run], dtype=torch.int64)
             dist.all_reduce(tot)
-            sent[impl] = int(tot.item())
+            sent[impl if partition == "naive" else impl + "+balanced"] = int(tot.item())
             op.close()
         assert sent["drop"] <= sent["baseline"], sent
         if rank == 0:

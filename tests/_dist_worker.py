@@ -30,9 +30,18 @@ def main():
     for name, A, N in cases:
         E = orc.spgemm(to_o(A), to_o(A))
         sent = {}
-        for impl in ("baseline", "drop", "shuffle"):
+        for impl in ("baseline", "drop", "shuffle", "drop+balanced"):
+            balanced = impl.endswith("+balanced")
+            impl = impl.split("+")[0]
             a_sh, b_sh = sd.make_shuffles(A.rows, A.cols, impl, seed=7)
-            parts = capi.partition_naive(A.rows, A.cols, world)
+            if balanced:  # rows cut by their share of the products (needs no pattern of C)
+                w = sd.row_products(A, A)
+                parts = capi.partition_balanced(w[a_sh], A.cols, world)
+                assert parts == orc.partition_balanced(w[a_sh], A.cols, world)
+                assert parts[0][0] == 0 and parts[-1][1] == A.rows
+                assert all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+            else:
+                parts = capi.partition_naive(A.rows, A.cols, world)
             ops = sd.build_rank_operands(A, A, rank, world, parts, a_sh, b_sh, N)
             bits = np.ones(N, dtype=bool) if impl == "baseline" else orc.section_bitmap(to_o(ops.A_part), N)
             bitmaps = sd.gather_bitmaps(bits, torch.device("cpu"))
@@ -67,7 +76,7 @@ def main():
                 orc.assert_same(to_o(M), E, rtol=0.0)
             tot = torch.tensor([ex.bytes_sent_per_run], dtype=torch.int64)
             dist.all_reduce(tot)
-            sent[impl] = int(tot.item())
+            sent[impl + ("+balanced" if balanced else "")] = int(tot.item())
         assert sent["drop"] <= sent["baseline"], sent
         if name == "band":
             assert sent["drop"] < sent["baseline"] // 2, sent  # banded: most sections are dropped
