@@ -83,6 +83,14 @@ def test_rmat_default_paths(ctx):
     check(ctx, A, A)
 
 
+def test_rmat_scale16_natural_big_rows(ctx):
+    """R-MAT scale 16, edge factor 8, default options: 5,127 rows of C have more than 4,096 entries
+    (the longest 28,892) and go through the big-row kernels with lists, slices and hub rows."""
+    A = hostcsr.rmat(16, 8, seed=1)
+    C, st = check(ctx, A, A)
+    assert st["rows_global"] > 5000 and C.nnz == 66874153
+
+
 def test_rmat_forced_hash_and_global(ctx):
     A = hostcsr.rmat(12, 8, seed=2)
     ctx.set_option("window_max_span", 0)
