@@ -83,12 +83,13 @@ def test_rmat_default_paths(ctx):
     check(ctx, A, A)
 
 
-def test_rmat_scale16_natural_big_rows(ctx):
-    """R-MAT scale 16, edge factor 8, default options: 5,127 rows of C have more than 4,096 entries
-    (the longest 28,892) and go through the big-row kernels with lists, slices and hub rows."""
-    A = hostcsr.rmat(16, 8, seed=1)
+def test_rmat_scale17_natural_big_rows(ctx):
+    """R-MAT scale 17, edge factor 8, default options: 13,741 rows of C have more than 4,096 entries
+    (the longest 54,278); with 131,072 columns the rows leave the window path and the big ones go
+    through the big-row kernels (bitmap windows; lists, slices and hub rows in the numeric pass)."""
+    A = hostcsr.rmat(17, 8, seed=1)
     C, st = check(ctx, A, A)
-    assert st["rows_global"] > 5000 and C.nnz == 66874153
+    assert st["rows_global"] > 10000 and C.nnz == 183630319
 
 
 def test_rmat_forced_hash_and_global(ctx):
