@@ -1,0 +1,342 @@
+// Numeric kernels of the window, row-group, LDS-hash and global-scratch paths; dropping exact zeros.
+// Part of the gfx950 SpGEMM kernels; included through kernels.h.
+#pragma once
+#include "kernels_walk.h"
+
+namespace sg {
+
+// ---- numeric -----------------------------------------------------------------------------------
+struct NumOut {
+  const uint64_t *__restrict__ c_ptr;
+  uint32_t *__restrict__ c_col;
+  double *__restrict__ c_val;
+  unsigned long long *zero_count; // entries whose accumulated value is exactly 0.0
+};
+
+// numeric, window path: one wavefront per row.
+// LDS per wavefront: bmp[words] of {lo: bitmap word, hi: number of set bits before the word}
+//                    | vals[cap] doubles | FLAT only: owner[cap] uint32 + flat-walk scratch.
+template <bool FLAT>
+__global__ void __launch_bounds__(256)
+    k_num_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                 uint32_t words, uint32_t cap, uint32_t wpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // one row per wavefront: scalar row state
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (size_t)cap * 8u + (FLAT ? (size_t)cap * 4u + FLAT_BYTES : 0u);
+  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  double *vals = reinterpret_cast<double *>(bmp + words);
+  uint32_t *owner = reinterpret_cast<uint32_t *>(vals + cap);
+  const uint32_t row = rows[idx];
+  const uint32_t base = m.cmin[row] & ~31u;
+  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
+  const uint32_t n = m.nnz[row];
+  const uint64_t off = o.c_ptr[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
+  for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
+  for (uint32_t i = lane; i < n; i += 64) {
+    vals[i] = 0.0;
+    if constexpr (FLAT) owner[i] = 0u;
+  }
+  lds_fence();
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t c = tin[p];
+    o.c_col[off + p] = c;
+    uint32_t cc = c - base;
+    atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<64>(pc);
+    if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  auto position = [&](uint32_t c) {
+    uint32_t cc = c - base;
+    uint64_t e = bmp[cc >> 5];
+    return (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+  };
+  if constexpr (FLAT) {
+    uint32_t stamp = 0;
+    flat_walk<true>(A, B, row, lane, reinterpret_cast<unsigned char *>(owner + cap),
+                    [&](uint32_t c, double bv, double av, uint32_t) {
+                      const bool live = c != EMPTY_KEY;
+                      const uint32_t pos = live ? position(c) : 0u;
+                      claim_in_lane_order(vals, owner, stamp, lane, live && pos < n, pos, __dmul_rn(av, bv));
+                    });
+  } else {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t pos = position(c);
+      if (pos < n) lds_add_f64(&vals[pos], __dmul_rn(av, bv));
+    });
+  }
+  lds_fence();
+  uint32_t nz = 0;
+  for (uint32_t p = lane; p < n; p += 64) {
+    double v = vals[p];
+    o.c_val[off + p] = v;
+    nz += (v == 0.0) ? 1u : 0u;
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, window path, row groups: one wavefront per group of up to GRP_MAX consecutive rows of
+// A that share their column list.  Every B entry is loaded once and its output position is found
+// once; it is then multiplied by each row's own A value (staged in LDS) and added to that row's
+// accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
+// LDS per wavefront: bmp[words] {bits, prefix} | vals[gmax][cap] | avals[gmax][alen], with
+// (gmax, alen) = (GRP_MAX, GRP_ALEN) or, for wide groups, (GRP_MAX_WIDE, GRP_ALEN_WIDE).
+template <bool WIDE>
+__global__ void __launch_bounds__(256)
+    k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                     uint32_t words, uint32_t cap, uint32_t wpb) {
+  constexpr uint32_t gmax = WIDE ? GRP_MAX_WIDE : GRP_MAX, alen = WIDE ? GRP_ALEN_WIDE : GRP_ALEN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
+  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  double *vals = reinterpret_cast<double *>(bmp + words);
+  double *avals = vals + (size_t)gmax * cap;
+  // row state through the scalar unit (all of it was written by earlier kernels)
+  const uint32_t row = scalar_view(rows)[idx];
+  const uint32_t cnt = min((uint32_t)scalar_view(m.gcnt)[row], gmax);
+  const uint32_t base = scalar_view(m.cmin)[row] & ~31u;
+  const uint32_t nw = ((scalar_view(m.cmax)[row] - base) >> 5) + 1u;
+  const uint32_t n = scalar_view((const uint32_t *)m.nnz)[row];
+  const uint32_t *tin = m.temp_cols + scalar_view(m.t_off)[row];
+  // first loads of the B walk, overlapped with the LDS set-up below
+  RowWalk<true, false> walk;
+  walk.begin(A, B, row, lane);
+  const uint32_t len_a = (uint32_t)(walk.a1 - walk.a0);
+  // lane j holds the output offset and the A offset of the group's j-th row
+  uint64_t my_off = 0, my_a = 0;
+  if (lane < cnt) {
+    my_off = o.c_ptr[row + lane];
+    my_a = A.ptr[row + lane];
+  }
+  for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
+#pragma unroll
+  for (uint32_t j = 0; j < GRP_MAX; ++j) {
+    if (j < cnt) {
+      for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
+      const double *av = A.val + readlane64(my_a, j);
+      for (uint32_t t = lane; t < len_a && t < alen; t += 64) avals[j * alen + t] = av[t];
+    }
+  }
+  lds_fence();
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t c = tin[p];
+#pragma unroll
+    for (uint32_t j = 0; j < GRP_MAX; ++j)
+      if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
+    uint32_t cc = c - base;
+    atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<64>(pc);
+    if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  walk.run(A, B, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
+    uint32_t cc = c - base;
+    uint64_t e = bmp[cc >> 5];
+    uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+    for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * alen + apos], bv));
+  });
+  lds_fence();
+  uint32_t nz = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < GRP_MAX; ++j) {
+    if (j < cnt) {
+      const uint64_t off = readlane64(my_off, j);
+      for (uint32_t p = lane; p < n; p += 64) {
+        double v = vals[j * cap + p];
+        o.c_val[off + p] = v;
+        nz += (v == 0.0) ? 1u : 0u;
+      }
+    }
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, hash path: one wavefront per row.
+// LDS per wavefront: vals[S/2] double | keys[S] uint32 | pos[S] uint16 (= 10*S bytes; nnz <= S/2)
+//                    | FLAT only: owner[S/2] uint32 + flat-walk scratch.
+// The sorted structural columns are inserted first (slot -> output position), so the
+// accumulate loop only probes (no compare-and-swap) and the output needs no sort.
+template <bool FLAT>
+__global__ void __launch_bounds__(256)
+    k_num_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+               uint32_t log2s, uint32_t wpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (w >= wpb || idx >= nrows) return;
+  const uint32_t S = 1u << log2s, mask = S - 1u;
+  const size_t region = (size_t)S * 10u + (FLAT ? (size_t)S * 2u + FLAT_BYTES : 0u);
+  unsigned char *reg = smem + w * region;
+  double *vals = reinterpret_cast<double *>(reg);                 // S/2 doubles = 4*S bytes
+  uint32_t *keys = reinterpret_cast<uint32_t *>(reg + 4u * S);    // S uint32
+  uint16_t *pos = reinterpret_cast<uint16_t *>(reg + 8u * S);     // S uint16
+  uint32_t *owner = reinterpret_cast<uint32_t *>(reg + 10u * S);  // S/2 uint32 (FLAT)
+  const uint32_t row = rows[idx];
+  const uint32_t n = m.nnz[row];
+  const uint64_t off = o.c_ptr[row];
+  const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
+  for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
+  for (uint32_t i = lane; i < n; i += 64) {
+    vals[i] = 0.0;
+    if constexpr (FLAT) owner[i] = 0u;
+  }
+  lds_fence();
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t c = tin[p];
+    o.c_col[off + p] = c;
+    uint32_t h = hash_slot(c, log2s);
+    uint32_t it = 0;
+    while (atomicCAS(&keys[h], EMPTY_KEY, c) != EMPTY_KEY && it < S) { h = (h + 1u) & mask; ++it; }
+    if (it < S) pos[h] = (uint16_t)p;
+  }
+  lds_fence();
+  // slot of column c (S when absent, which cannot happen for a consistent symbolic result)
+  auto find = [&](uint32_t c) {
+    uint32_t h = hash_slot(c, log2s);
+    uint32_t it = 0;
+    while (keys[h] != c && it < S) { h = (h + 1u) & mask; ++it; }
+    return it < S ? h : S;
+  };
+  if constexpr (FLAT) {
+    uint32_t stamp = 0;
+    flat_walk<true>(A, B, row, lane, reg + 12u * S, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t h = c != EMPTY_KEY ? find(c) : S;
+      const bool live = h < S;
+      claim_in_lane_order(vals, owner, stamp, lane, live, live ? (uint32_t)pos[h] : 0u, __dmul_rn(av, bv));
+    });
+  } else {
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
+      const uint32_t h = find(c);
+      if (h < S) lds_add_f64(&vals[pos[h]], __dmul_rn(av, bv));
+    });
+  }
+  lds_fence();
+  uint32_t nz = 0;
+  for (uint32_t p = lane; p < n; p += 64) {
+    double v = vals[p];
+    o.c_val[off + p] = v;
+    nz += (v == 0.0) ? 1u : 0u;
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// numeric, global path: ONE wavefront per row (the k order must be kept), accumulating straight
+// into the row's slice of c_val through L2 atomics.  scratch: per workgroup `words_total`
+// {bitmap word, prefix} pairs, all zero on entry and on exit.
+__global__ void __launch_bounds__(64)
+    k_num_global(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
+                 unsigned long long *__restrict__ scratch, uint64_t words_total) {
+  unsigned long long *bmp = scratch + (size_t)blockIdx.x * words_total;
+  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t idx = blockIdx.x; idx < nrows; idx += gridDim.x) {
+    const uint32_t row = rows[idx];
+    const uint32_t n = m.nnz[row];
+    const uint64_t off = o.c_ptr[row];
+    const uint32_t *tin = m.temp_cols + m.t_off[m.lead[row]];
+    const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
+    for (uint32_t p = lane; p < n; p += 64) {
+      uint32_t c = tin[p];
+      o.c_col[off + p] = c;
+      __hip_atomic_store(&o.c_val[off + p], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicOr(&bmp32[(size_t)(c >> 5) * 2u], 1u << (c & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    uint32_t carry = 0;
+    for (uint32_t r0 = w0; r0 <= w1; r0 += 64) {
+      uint32_t wi = r0 + lane;
+      uint32_t bits = 0;
+      if (wi <= w1) bits = __hip_atomic_load(&bmp32[(size_t)wi * 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t pc = __popc(bits);
+      uint32_t incl = group_incl_scan<64>(pc);
+      if (wi <= w1 && bits)
+        __hip_atomic_store(&bmp32[(size_t)wi * 2u + 1u], carry + incl - pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      carry += group_last<64>(incl);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
+      unsigned long long e = __hip_atomic_load(&bmp[c >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (c & 31u)) - 1u));
+      if (pos < n) unsafeAtomicAdd(&o.c_val[off + pos], __dmul_rn(av, bv));
+    });
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    uint32_t nz = 0;
+    for (uint32_t p = lane; p < n; p += 64) {
+      double v = __hip_atomic_load(&o.c_val[off + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nz += (v == 0.0) ? 1u : 0u;
+      uint32_t c = tin[p];
+      __hip_atomic_store(&bmp[c >> 5], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    nz = group_sum<64>(nz);
+    if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
+}
+
+// ---- dropping exact zeros (rare) ----------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_count_nonzero(uint32_t rows, const uint64_t *__restrict__ c_ptr, const double *__restrict__ c_val,
+                    uint32_t *__restrict__ keep) {
+  constexpr int G = 8;
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t cnt = 0;
+  if (row < rows)
+    for (uint64_t j = c_ptr[row] + lg; j < c_ptr[row + 1]; j += G) cnt += (c_val[j] != 0.0) ? 1u : 0u;
+  cnt = group_sum<G>(cnt);
+  if (row < rows && lg == 0) keep[row] = cnt;
+}
+
+// one wavefront per row, order-preserving
+__global__ void __launch_bounds__(256)
+    k_compact_rows(uint32_t rows, const uint64_t *__restrict__ old_ptr, const uint32_t *__restrict__ old_col,
+                   const double *__restrict__ old_val, const uint64_t *__restrict__ new_ptr,
+                   uint32_t *__restrict__ new_col, double *__restrict__ new_val) {
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  uint64_t j0 = old_ptr[row], j1 = old_ptr[row + 1];
+  uint64_t out = new_ptr[row];
+  for (uint64_t jb = j0; jb < j1; jb += 64) {
+    uint64_t j = jb + lane;
+    double v = j < j1 ? old_val[j] : 0.0;
+    bool keepit = j < j1 && v != 0.0;
+    unsigned long long mball = __ballot(keepit);
+    if (keepit) {
+      uint64_t p = out + __popcll(mball & ((1ull << lane) - 1ull));
+      new_col[p] = old_col[j];
+      new_val[p] = v;
+    }
+    out += __popcll(mball);
+  }
+}
+
+} // namespace sg

@@ -1,0 +1,379 @@
+// Per-multiply preparation: B row info, A row analysis, row groups, exclusive scan, stable partition of rows by bin.
+// Part of the gfx950 SpGEMM kernels; included through kernels.h.
+#pragma once
+#include "kernels_common.h"
+
+namespace sg {
+
+// ---- B row info: {min col, max col, length, 1 if the row's columns are not strictly increasing}
+// of every B row; info[rows].x counts the rows that are not strictly increasing (zero on entry).
+// 8 lanes per row.
+__global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
+                                                   const uint32_t *__restrict__ b_col,
+                                                   uint4 *__restrict__ info) {
+  constexpr int G = 8;
+  uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t mn = 0xFFFFFFFFu, mx = 0, unsorted = 0;
+  uint64_t b0 = 0, b1 = 0;
+  if (row < rows) {
+    b0 = b_ptr[row];
+    b1 = b_ptr[row + 1];
+  }
+  for (uint64_t j = b0 + lg; j < b1; j += G) {
+    uint32_t c = b_col[j];
+    if (j > b0 && b_col[j - 1] >= c) unsorted = 1;
+    mn = min(mn, c);
+    mx = max(mx, c);
+  }
+  mn = group_min<G>(mn);
+  mx = group_max<G>(mx);
+  unsorted = group_max<G>(unsorted);
+  if (row < rows && lg == 0) {
+    uint64_t len = b1 - b0;
+    info[row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
+    if (unsorted) atomicAdd(&info[rows].x, 1u);
+  }
+}
+
+// ---- A row analysis --------------------------------------------------------------------------
+// Per A row: nprod = sum of B row lengths, [cmin, cmax] = hull of the B rows' column ranges,
+// the symbolic bin key and the upper bound `ub` on the row's distinct columns.
+constexpr uint32_t NPROD_SLOTS = 256;
+struct AnalyzeOut {
+  uint32_t *r_cmin;
+  uint32_t *r_cmax;
+  uint32_t *r_ub;
+  uint8_t *r_key;
+  uint64_t *r_nprod;       // optional (may be null)
+  uint64_t *total_nprod;   // NPROD_SLOTS partial counters, summed by the host
+  uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
+  uint32_t *long_count;
+  uint8_t *r_same;         // 1 when the row's column list equals the previous row's (same order)
+};
+
+__device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32_t mn, uint32_t mx,
+                                               uint32_t len_a, const AnalyzeOut &o,
+                                               const ClassParams &cp) {
+  uint32_t span = np ? (mx - mn + 1u) : 0u;
+  uint32_t key = sym_key_of(np, span, len_a, cp);
+  uint64_t ub = np;
+  if (key != KEY_NONE && (key < (uint32_t)SYM_HASH0 || key >= (uint32_t)SYM_GLOBAL0))
+    ub = np < span ? np : span;
+  o.r_cmin[row] = mn;
+  o.r_cmax[row] = mx;
+  o.r_ub[row] = (uint32_t)ub;
+  o.r_key[row] = (uint8_t)key;
+  if (o.r_nprod) o.r_nprod[row] = np;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+    k_analyze(uint32_t rows_a, const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
+              const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp, uint32_t long_len) {
+  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint64_t np = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  uint64_t a0 = 0, a1 = 0;
+  bool is_long = false;
+  if (row < rows_a) {
+    a0 = a_ptr[row];
+    a1 = a_ptr[row + 1];
+    is_long = (a1 - a0) > long_len;
+  }
+  uint32_t differs = 1;
+  if (!is_long) {
+    // does the row repeat the previous row's column list?
+    uint64_t p0 = 0;
+    bool cmp = false;
+    if (row > 0 && row < rows_a) {
+      p0 = a_ptr[row - 1];
+      cmp = (a0 - p0) == (a1 - a0) && a1 > a0;
+    }
+    differs = cmp ? 0u : 1u;
+    for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
+      uint32_t kcol = a_col[ka];
+      if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
+      uint4 bi = b_info[kcol];
+      if (bi.z) {
+        np += bi.z;
+        mn = min(mn, bi.x);
+        mx = max(mx, bi.y);
+      }
+    }
+  }
+  differs = group_max<G>(differs);
+  np = group_sum64<G>(np);
+  mn = group_min<G>(mn);
+  mx = group_max<G>(mx);
+  uint64_t contrib = 0;
+  if (row < rows_a && lg == 0) {
+    o.r_same[row] = differs ? 0 : 1;
+    if (is_long) {
+      uint32_t p = atomicAdd(o.long_count, 1u);
+      o.long_rows[p] = row;
+    } else {
+      analyze_finish(row, np, mn, mx, (uint32_t)(a1 - a0), o, cp);
+      contrib = np;
+    }
+  }
+  // product total: reduce over the workgroup, then one atomic per workgroup, spread over
+  // NPROD_SLOTS counters (atomics on a single word would serialise the whole grid)
+  __shared__ uint64_t s_c[4];
+  contrib = group_sum64<64>(contrib);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    if (t) atomicAdd((unsigned long long *)&o.total_nprod[blockIdx.x & (NPROD_SLOTS - 1)], (unsigned long long)t);
+  }
+}
+
+// One 256-thread workgroup per long A row.
+__global__ void __launch_bounds__(256)
+    k_analyze_long(const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
+                   const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp) {
+  __shared__ uint64_t s_np[4];
+  __shared__ uint32_t s_mn[4], s_mx[4];
+  uint32_t nlong = *o.long_count;
+  for (uint32_t idx = blockIdx.x; idx < nlong; idx += gridDim.x) {
+    uint32_t row = o.long_rows[idx];
+    uint64_t a0 = a_ptr[row], a1 = a_ptr[row + 1];
+    uint64_t np = 0;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (uint64_t ka = a0 + threadIdx.x; ka < a1; ka += blockDim.x) {
+      uint4 bi = b_info[a_col[ka]];
+      if (bi.z) {
+        np += bi.z;
+        mn = min(mn, bi.x);
+        mx = max(mx, bi.y);
+      }
+    }
+    np = group_sum64<64>(np);
+    mn = group_min<64>(mn);
+    mx = group_max<64>(mx);
+    uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      s_np[w] = np;
+      s_mn[w] = mn;
+      s_mx[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      np = s_np[0] + s_np[1] + s_np[2] + s_np[3];
+      mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+      mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+      analyze_finish(row, np, mn, mx, (uint32_t)(a1 - a0), o, cp);
+      if (np) atomicAdd((unsigned long long *)&o.total_nprod[blockIdx.x & (NPROD_SLOTS - 1)], (unsigned long long)np);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- row groups ----------------------------------------------------------------------------------
+// Consecutive rows of A with identical column lists (the unknowns of one mesh node, for example)
+// produce identical patterns in C and walk the same B rows.  Such runs are cut into groups of
+// up to GRP_MAX rows; the first row of a group is its leader.  The symbolic pass runs once per
+// group, and the numeric pass loads every B entry and finds its output position once per group,
+// then adds into one accumulator per row.  Only window-path rows with at most GRP_ALEN A
+// entries are grouped.  gcnt: rows in the group for a leader (>= 1), 0 for a follower.
+// Every row decides for itself from the `same` flags around it; the rule (position inside the
+// run modulo GRP_MAX, runs longer than 56 rows stop grouping) gives the same answer from the
+// leader's and from the follower's point of view.
+__global__ void __launch_bounds__(256)
+    k_group(uint32_t rows, const uint64_t *__restrict__ a_ptr, const uint8_t *__restrict__ same,
+            uint8_t *__restrict__ key, uint32_t *__restrict__ ub, uint8_t *__restrict__ gcnt,
+            uint32_t *__restrict__ lead, uint32_t enable) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  lead[i] = i;
+  const uint32_t k = key[i];
+  const uint64_t len = a_ptr[i + 1] - a_ptr[i];
+  if (!enable || k >= (uint32_t)SYM_HASH0 || len > GRP_ALEN_WIDE) { // not a window row (or no products)
+    gcnt[i] = 1;
+    return;
+  }
+  uint32_t pos = 0; // rows before i that belong to the same run
+  while (pos < 56u && pos < i && same[i - pos]) ++pos;
+  if (pos >= 56u) {
+    gcnt[i] = 1;
+    return;
+  }
+  const uint32_t gmax = group_max_rows(len); // the rows of a run have the same length
+  if (pos % gmax != 0) { // follower: handled by its leader
+    gcnt[i] = 0;
+    key[i] = (uint8_t)KEY_NONE;
+    ub[i] = 0;
+    lead[i] = i - pos % gmax;
+    return;
+  }
+  uint32_t c = 1;
+  while (c < gmax && i + c < rows && same[i + c]) ++c;
+  gcnt[i] = (uint8_t)c;
+}
+
+// ---- exclusive scan (uint32 in, uint64 out), three launches ----------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8; // per thread -> 2048 per workgroup
+
+__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t *s_wave /*>=4*/, uint64_t *total) {
+  // inclusive scan inside the wavefront
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t t = __shfl_up(x, d, 64);
+    if (lane >= d) x += t;
+  }
+  if (lane == 63) s_wave[w] = x;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) {
+    if (i < w) base += s_wave[i];
+    tot += s_wave[i];
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK)
+    k_scan_partials(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ partial) {
+  __shared__ uint64_t s_wave[4];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + (uint64_t)i * SCAN_BLOCK + threadIdx.x;
+    if (idx < n) s += in[idx];
+  }
+  uint64_t tot;
+  block_excl_scan64(s, s_wave, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the partials in place; total -> partial[nparts]
+__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *partial, uint32_t nparts) {
+  __shared__ uint64_t s_wave[16];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nparts; base += 1024) {
+    uint32_t idx = base + threadIdx.x;
+    uint64_t v = idx < nparts ? partial[idx] : 0;
+    uint64_t tot;
+    uint64_t ex = block_excl_scan64(v, s_wave, &tot);
+    uint64_t carry = s_carry;
+    if (idx < nparts) partial[idx] = ex + carry;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[nparts] = s_carry;
+}
+
+// out[i] = exclusive prefix; out[n] = total.  Items are laid out thread-contiguous here so the
+// per-thread prefix is a running sum.
+__global__ void __launch_bounds__(SCAN_BLOCK)
+    k_scan_final(const uint32_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ partial,
+                 uint64_t *__restrict__ out, uint32_t nparts) {
+  __shared__ uint64_t s_wave[4];
+  __shared__ uint32_t s_items[SCAN_BLOCK * SCAN_ITEMS];
+  uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint32_t l = i * SCAN_BLOCK + threadIdx.x;
+    uint64_t idx = base + l;
+    s_items[l] = idx < n ? in[idx] : 0u;
+  }
+  __syncthreads();
+  uint32_t v[SCAN_ITEMS];
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = s_items[threadIdx.x * SCAN_ITEMS + i];
+    s += v[i];
+  }
+  uint64_t ex = block_excl_scan64(s, s_wave, nullptr) + partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    uint64_t idx = base + (uint64_t)threadIdx.x * SCAN_ITEMS + i;
+    if (idx < n) out[idx] = ex;
+    ex += v[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nparts];
+}
+
+// ---- stable partition of rows by an 8-bit key ---------------------------------------------------
+constexpr int PART_BLOCK = 256;
+constexpr int PART_ROUNDS = 4; // 1024 rows per workgroup
+
+__global__ void __launch_bounds__(PART_BLOCK)
+    k_part_hist(const uint8_t *__restrict__ key, uint32_t n, uint32_t nbins, uint32_t nblocks,
+                uint32_t *__restrict__ blk_hist /* [nbins][nblocks] */) {
+  __shared__ uint32_t s_h[MAX_BINS];
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) s_h[b] = 0;
+  __syncthreads();
+  uint32_t base = blockIdx.x * PART_BLOCK * PART_ROUNDS;
+  for (int r = 0; r < PART_ROUNDS; ++r) {
+    uint32_t i = base + r * PART_BLOCK + threadIdx.x;
+    if (i < n) {
+      uint32_t k = key[i];
+      if (k < nbins) atomicAdd(&s_h[k], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) blk_hist[(size_t)b * nblocks + blockIdx.x] = s_h[b];
+}
+
+// blk_off = exclusive scan of blk_hist (bin-major), so bin b starts at blk_off[b*nblocks].
+__global__ void __launch_bounds__(PART_BLOCK)
+    k_part_scatter(const uint8_t *__restrict__ key, uint32_t n, uint32_t nbins, uint32_t nblocks,
+                   const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ rows_out) {
+  __shared__ uint32_t s_base[MAX_BINS];
+  __shared__ uint32_t s_wcnt[4][MAX_BINS];
+  for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK)
+    s_base[b] = (uint32_t)blk_off[(size_t)b * nblocks + blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t base = blockIdx.x * PART_BLOCK * PART_ROUNDS;
+  for (int r = 0; r < PART_ROUNDS; ++r) {
+    for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK) {
+      s_wcnt[0][b] = 0; s_wcnt[1][b] = 0; s_wcnt[2][b] = 0; s_wcnt[3][b] = 0;
+    }
+    __syncthreads();
+    uint32_t i = base + r * PART_BLOCK + threadIdx.x;
+    uint32_t k = i < n ? key[i] : KEY_NONE;
+    bool valid = k < nbins;
+    uint32_t rank = 0;
+    unsigned long long left = __ballot(valid);
+    while (left) {
+      int leader = __ffsll((long long)left) - 1;
+      uint32_t kb = __shfl(k, leader, 64);
+      unsigned long long m = __ballot(valid && k == kb);
+      if (valid && k == kb) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if ((int)lane == leader) s_wcnt[w][kb] = __popcll(m);
+      left &= ~m;
+    }
+    __syncthreads();
+    if (valid) {
+      uint32_t off = s_base[k] + rank;
+      for (uint32_t ww = 0; ww < w; ++ww) off += s_wcnt[ww][k];
+      rows_out[off] = i;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK)
+      s_base[b] += s_wcnt[0][b] + s_wcnt[1][b] + s_wcnt[2][b] + s_wcnt[3][b];
+    __syncthreads();
+  }
+}
+
+// bin_off[b] = start of bin b in rows_out (b = 0..nbins), read from the scanned histogram.
+__global__ void k_part_binoff(const uint64_t *__restrict__ blk_off, uint32_t nbins, uint32_t nblocks,
+                              uint64_t *__restrict__ bin_off) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nbins) bin_off[b] = blk_off[(size_t)b * nblocks];
+}
+
+} // namespace sg

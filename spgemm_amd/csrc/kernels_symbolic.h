@@ -1,0 +1,295 @@
+// Symbolic kernels of the window, LDS-hash and global-scratch paths.
+// Part of the gfx950 SpGEMM kernels; included through kernels.h.
+#pragma once
+#include "kernels_walk.h"
+
+namespace sg {
+
+// ---- symbolic, window path: one wavefront per row ------------------------------------------------
+// LDS per wavefront: `words` pairs {bitmap word, number of set bits before it} covering columns
+// [cmin & ~31, cmax].
+//
+// Every product ORs its bit into the bitmap (lanes of one instruction that share a word are
+// serialised by the LDS; combining them first in registers was measured and cost more than it
+// saved).  The sorted column list is then written coalesced: output position p finds the word
+// that holds the p-th set bit by a binary search over the per-word prefix counts.
+// FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
+template <bool FLAT>
+__global__ void __launch_bounds__(256)
+    k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+                 uint32_t words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform on the scalar unit
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (idx >= nrows) return;
+  const size_t region = (size_t)words * 8u + (FLAT ? FLAT_BYTES : 0u);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);
+  const uint32_t row = rows[idx];
+  const uint32_t base = m.cmin[row] & ~31u;
+  const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
+  for (uint32_t i = lane; i < nw; i += 64) reinterpret_cast<uint64_t *>(bm)[i] = 0ull;
+  lds_fence();
+  auto mark = [&](uint32_t col, double, double, uint32_t) {
+    if (col == EMPTY_KEY) return;
+    uint32_t c = col - base;
+    atomicOr(&bm[(c >> 5) * 2u], 1u << (c & 31u));
+  };
+  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)words * 8u, mark);
+  else wave_row_walk<false>(A, B, row, lane, mark);
+  lds_fence();
+  // per-word prefix of the set-bit counts
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    uint32_t wi = r0 + lane;
+    uint32_t pc = wi < nw ? __popc(bm[wi * 2u]) : 0u;
+    uint32_t incl = group_incl_scan<64>(pc);
+    if (wi < nw) bm[wi * 2u + 1u] = carry + incl - pc;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  // output position p -> word holding the p-th set bit (binary search on the prefixes) -> column
+  const uint32_t n = carry;
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t lo = 0, hi = nw - 1u;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi + 1u) >> 1;
+      if (bm[mid * 2u + 1u] <= p) lo = mid; else hi = mid - 1u;
+    }
+    uint2 e = *reinterpret_cast<const uint2 *>(&bm[lo * 2u]);
+    out[p] = base + (lo << 5) + select_bit(e.x, p - e.y);
+  }
+  // the group's rows share the pattern: same nnz; they are accumulated together when the group
+  // kernel has a tier for them, else one by one (each reading the leader's column list)
+  const uint32_t cnt = m.gcnt[row];
+  if (lane < cnt) {
+    m.nnz[row + lane] = n;
+    const bool wide = A.ptr[row + 1] - A.ptr[row] > GRP_ALEN;
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, wide);
+    const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
+    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
+  }
+}
+
+// ---- symbolic, hash path: one wavefront per row ----------------------------------------------
+// LDS per wavefront: keys[S] | cnt[S/2] | tk[S/2]  (uint32 each) = 8*S bytes, S = 1 << log2s.
+// S >= 2 * nprod, so the table is at most half full.  Sorting is a bucket rank sort: a monotone
+// map of the column into S/2 buckets, counting sort into bucket order, then each key finds its
+// rank among the (few) keys of its bucket.
+template <bool FLAT>
+__global__ void __launch_bounds__(256)
+    k_sym_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+               uint32_t log2s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  if (idx >= nrows) return;
+  const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
+  const size_t region = (size_t)S * 8u + (FLAT ? FLAT_BYTES : 0u);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
+  uint32_t *cnt = keys + S;
+  uint32_t *tk = cnt + NB;
+  const uint32_t row = rows[idx];
+  for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
+  for (uint32_t i = lane; i < NB; i += 64) cnt[i] = 0u;
+  lds_fence();
+  uint32_t mine = 0;
+  auto insert = [&](uint32_t c, double, double, uint32_t) {
+    if (c == EMPTY_KEY) return;
+    uint32_t h = hash_slot(c, log2s);
+    for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+      uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+      if (old == EMPTY_KEY) { ++mine; break; }
+      if (old == c) break;
+      h = (h + 1u) & mask;
+    }
+  };
+  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)S * 8u, insert);
+  else wave_row_walk<false>(A, B, row, lane, insert);
+  lds_fence();
+  const uint32_t n = group_sum<64>(mine);
+  const uint32_t cmin = m.cmin[row];
+  const float scale = (float)NB / (float)(m.cmax[row] - cmin + 1u);
+  // pass A: bucket counts
+  for (uint32_t s = lane; s < S; s += 64) {
+    uint32_t key = keys[s];
+    if (key != EMPTY_KEY) {
+      uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+      atomicAdd(&cnt[b], 1u);
+    }
+  }
+  lds_fence();
+  // exclusive scan of cnt
+  uint32_t carry = 0;
+  for (uint32_t r0 = 0; r0 < NB; r0 += 64) {
+    uint32_t v = cnt[r0 + lane]; // NB is a multiple of 64
+    uint32_t incl = group_incl_scan<64>(v);
+    cnt[r0 + lane] = carry + incl - v;
+    carry += group_last<64>(incl);
+  }
+  lds_fence();
+  // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
+  for (uint32_t s = lane; s < S; s += 64) {
+    uint32_t key = keys[s];
+    if (key != EMPTY_KEY) {
+      uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+      uint32_t p = atomicAdd(&cnt[b], 1u);
+      tk[p] = key;
+    }
+  }
+  lds_fence();
+  // pass C: rank inside the bucket, write sorted
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = lane; p < n; p += 64) {
+    uint32_t key = tk[p];
+    uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+    uint32_t start = b ? cnt[b - 1] : 0u, end = cnt[b];
+    uint32_t rank = start;
+    for (uint32_t q = start; q < end; ++q) rank += (tk[q] < key) ? 1u : 0u;
+    out[rank] = key;
+  }
+  if (lane == 0) {
+    m.nnz[row] = n;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
+  }
+}
+
+// ---- symbolic, hash path, large tables: one 256-thread workgroup per row ---------------------------
+// The same algorithm as k_sym_hash with the four wavefronts of a workgroup sharing one table (the
+// pattern of a row does not depend on the order in which its products are seen): a table of 8192
+// slots takes 64 KiB of LDS, and one wavefront per table would leave two wavefronts on a CU.
+// The wavefronts take the A entries round robin.  LDS: keys[S] | cnt[S/2] | tk[S/2] = 8*S bytes.
+__global__ void __launch_bounds__(256)
+    k_sym_hash_wg(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_n, s_wsum[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *cnt = keys + S;
+  uint32_t *tk = cnt + NB;
+  const uint32_t row = scalar_view(rows)[xcd_remap(blockIdx.x, gridDim.x)];
+  for (uint32_t i = tid; i < S; i += 256) keys[i] = EMPTY_KEY;
+  for (uint32_t i = tid; i < NB; i += 256) cnt[i] = 0u;
+  if (tid == 0) s_n = 0u;
+  __syncthreads();
+  const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
+  uint32_t mine = 0;
+  for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
+    const uint32_t k = scalar_view(A.col)[ka];
+    const uint64_t b0 = scalar_view(B.ptr)[k], b1 = scalar_view(B.ptr)[k + 1];
+    for (uint64_t j = b0 + lane; j < b1; j += 64) {
+      const uint32_t c = B.col[j];
+      uint32_t h = hash_slot(c, log2s);
+      for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+        const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+        if (old == EMPTY_KEY) { ++mine; break; }
+        if (old == c) break;
+        h = (h + 1u) & mask;
+      }
+    }
+  }
+  mine = group_last<64>(group_incl_scan<64>(mine));
+  if (lane == 0 && mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  const uint32_t n = s_n;
+  const uint32_t cmin = m.cmin[row];
+  const float scale = (float)NB / (float)(m.cmax[row] - cmin + 1u);
+  // pass A: bucket counts (buckets are monotone in the column)
+  for (uint32_t s = tid; s < S; s += 256) {
+    const uint32_t key = keys[s];
+    if (key != EMPTY_KEY) atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of cnt: NB / 256 consecutive buckets per thread (NB is a multiple of 256 here)
+  const uint32_t per = NB >> 8;
+  uint32_t local = 0;
+  for (uint32_t i = 0; i < per; ++i) local += cnt[tid * per + i];
+  const uint32_t incl = group_incl_scan<64>(local);
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  uint32_t run = incl - local;
+  for (uint32_t i = 0; i < w; ++i) run += s_wsum[i];
+  for (uint32_t i = 0; i < per; ++i) {
+    const uint32_t v = cnt[tid * per + i];
+    cnt[tid * per + i] = run;
+    run += v;
+  }
+  __syncthreads();
+  // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
+  for (uint32_t s = tid; s < S; s += 256) {
+    const uint32_t key = keys[s];
+    if (key != EMPTY_KEY) tk[atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u)] = key;
+  }
+  __syncthreads();
+  // pass C: rank inside the bucket, write sorted
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  for (uint32_t p = tid; p < n; p += 256) {
+    const uint32_t key = tk[p];
+    const uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
+    const uint32_t start = b ? cnt[b - 1] : 0u, end = cnt[b];
+    uint32_t rank = start;
+    for (uint32_t q = start; q < end; ++q) rank += (tk[q] < key) ? 1u : 0u;
+    out[rank] = key;
+  }
+  if (tid == 0) {
+    m.nnz[row] = n;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
+  }
+}
+
+// ---- symbolic, global path: one 256-thread workgroup per row, bitmap in global scratch ---------
+// scratch: per workgroup `words_total` uint32 words, all zero on entry and on exit.
+__global__ void __launch_bounds__(256)
+    k_sym_global(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
+                 uint32_t *__restrict__ scratch, uint64_t words_total) {
+  __shared__ uint64_t s_wave[4];
+  __shared__ uint32_t s_carry;
+  uint32_t *bm = scratch + (size_t)blockIdx.x * words_total;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t idx = blockIdx.x; idx < nrows; idx += gridDim.x) {
+    const uint32_t row = rows[idx];
+    const uint32_t w0 = m.cmin[row] >> 5, w1 = m.cmax[row] >> 5;
+    const uint64_t a0 = A.ptr[row], a1 = A.ptr[row + 1];
+    for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
+      uint32_t k = A.col[ka];
+      uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+      for (uint64_t jb = b0 + lane; jb < b1; jb += 64) {
+        uint32_t c = B.col[jb];
+        atomicOr(&bm[c >> 5], 1u << (c & 31u));
+      }
+    }
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    uint32_t *out = m.temp_cols + m.t_off[row];
+    for (uint32_t r0 = w0; r0 <= w1; r0 += 256) {
+      uint32_t wi = r0 + threadIdx.x;
+      uint32_t bits = 0;
+      if (wi <= w1) bits = atomicExch(&bm[wi], 0u); // read through L2 and clear
+      uint32_t pc = __popc(bits);
+      uint64_t tot;
+      uint32_t ex = (uint32_t)block_excl_scan64(pc, s_wave, &tot);
+      uint32_t pos = s_carry + ex;
+      uint32_t cbase = wi << 5;
+      while (bits) {
+        uint32_t b = __ffs(bits) - 1;
+        out[pos++] = cbase + b;
+        bits &= bits - 1u;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_carry += (uint32_t)tot;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      uint32_t n = s_carry;
+      m.nnz[row] = n;
+      m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], n, m.hash_num_max);
+    }
+    __syncthreads();
+  }
+}
+
+} // namespace sg

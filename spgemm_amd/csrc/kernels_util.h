@@ -1,0 +1,123 @@
+// Section bitmap, per-launch accounting, validation, operand selection, B exchange helpers.
+// Part of the gfx950 SpGEMM kernels; included through kernels.h.
+#pragma once
+#include "kernels_common.h"
+
+namespace sg {
+
+// ---- section bitmap (reference src/bitmap.cpp:12-40) ---------------------------------------------
+constexpr uint32_t MAX_SECTIONS = 4096;
+__global__ void __launch_bounds__(256)
+    k_section_bitmap(uint64_t nnz, const uint32_t *__restrict__ a_col, uint32_t section_width,
+                     uint32_t n_sections, uint32_t *__restrict__ words /* ceil(n/32), pre-zeroed */) {
+  __shared__ uint32_t s_bits[MAX_SECTIONS / 32];
+  const uint32_t nwords = (n_sections + 31u) >> 5;
+  for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) s_bits[i] = 0u;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t s = min(a_col[i] / section_width, n_sections - 1u);
+    uint32_t bit = 1u << (s & 31u);
+    if (!(s_bits[s >> 5] & bit)) atomicOr(&s_bits[s >> 5], bit);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x)
+    if (s_bits[i]) atomicOr(&words[i], s_bits[i]);
+}
+
+// ---- per-launch accounting (profile mode): sums over the rows of one bin --------------------------
+__global__ void __launch_bounds__(256)
+    k_bin_sums(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
+               const uint64_t *__restrict__ r_nprod, const uint32_t *__restrict__ r_nnz,
+               const uint8_t *__restrict__ gcnt, uint32_t whole_groups,
+               unsigned long long *__restrict__ out /* nnz_a, nprod, nnz_c */) {
+  uint64_t sa = 0, sp = 0, sc = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
+    uint32_t r = rows[i];
+    uint64_t mult = whole_groups ? max((uint32_t)gcnt[r], 1u) : 1u; // the launch handled the whole group
+    sa += mult * (a_ptr[r + 1] - a_ptr[r]);
+    sp += mult * r_nprod[r];
+    sc += mult * r_nnz[r];
+  }
+  sa = group_sum64<64>(sa);
+  sp = group_sum64<64>(sp);
+  sc = group_sum64<64>(sc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)sa);
+    atomicAdd(&out[1], (unsigned long long)sp);
+    atomicAdd(&out[2], (unsigned long long)sc);
+  }
+}
+
+// ---- validation ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_validate(uint64_t rows, uint64_t cols, uint64_t nnz, const uint64_t *__restrict__ ptr,
+               const uint32_t *__restrict__ col, uint32_t *__restrict__ bad) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t r = i; r < rows; r += stride)
+    if (ptr[r] > ptr[r + 1] || ptr[r + 1] > nnz) atomicOr(bad, 1u);
+  if (i == 0 && (ptr[0] != 0 || ptr[rows] != nnz)) atomicOr(bad, 2u);
+  for (uint64_t j = i; j < nnz; j += stride)
+    if ((uint64_t)col[j] >= cols) atomicOr(bad, 4u);
+}
+
+// ---- operand selection (keep_rows / column relabel) ------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_select_count(uint64_t n_out, const uint32_t *__restrict__ keep_rows, const uint64_t *__restrict__ ptr,
+                   const uint32_t *__restrict__ col, const uint32_t *__restrict__ col_new,
+                   uint32_t *__restrict__ out_len) {
+  constexpr int G = 8;
+  uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t cnt = 0;
+  if (r < n_out) {
+    uint64_t src = keep_rows ? keep_rows[r] : r;
+    uint64_t j0 = ptr[src], j1 = ptr[src + 1];
+    if (col_new) {
+      for (uint64_t j = j0 + lg; j < j1; j += G) cnt += (col_new[col[j]] != 0xFFFFFFFFu) ? 1u : 0u;
+    } else if (lg == 0) {
+      cnt = (uint32_t)(j1 - j0);
+    }
+  }
+  cnt = group_sum<G>(cnt);
+  if (r < n_out && lg == 0) out_len[r] = cnt;
+}
+
+// one wavefront per output row, order-preserving copy with relabel
+__global__ void __launch_bounds__(256)
+    k_select_copy(uint64_t n_out, const uint32_t *__restrict__ keep_rows, const uint64_t *__restrict__ ptr,
+                  const uint32_t *__restrict__ col, const double *__restrict__ val,
+                  const uint32_t *__restrict__ col_new, const uint64_t *__restrict__ out_ptr,
+                  uint32_t *__restrict__ out_col, double *__restrict__ out_val) {
+  uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t lane = threadIdx.x & 63;
+  if (r >= n_out) return;
+  uint64_t src = keep_rows ? keep_rows[r] : r;
+  uint64_t j0 = ptr[src], j1 = ptr[src + 1];
+  uint64_t out = out_ptr[r];
+  for (uint64_t jb = j0; jb < j1; jb += 64) {
+    uint64_t j = jb + lane;
+    uint32_t c = 0xFFFFFFFFu;
+    if (j < j1) {
+      c = col[j];
+      if (col_new) c = col_new[c];
+    }
+    bool keepit = j < j1 && c != 0xFFFFFFFFu;
+    unsigned long long mball = __ballot(keepit);
+    if (keepit) {
+      uint64_t p = out + __popcll(mball & ((1ull << lane) - 1ull));
+      out_col[p] = c;
+      out_val[p] = val[j];
+    }
+    out += __popcll(mball);
+  }
+}
+
+// ---- B exchange helpers ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_row_len(uint64_t rows, const uint64_t *__restrict__ ptr, uint32_t *__restrict__ len) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) len[r] = (uint32_t)(ptr[r + 1] - ptr[r]);
+}
+
+} // namespace sg
