@@ -232,6 +232,8 @@ class SectionExchange:
         self.present_idx = torch.from_numpy(np.flatnonzero(present)).to(device)
         self.bytes_sent_per_run = sum(4 * r + 12 * z for d, (r, z) in enumerate(zip(self.send_rows, self.send_nnz))
                                       if d != self.rank)
+        # what this rank would send if every peer took all of its sections (no bitmap)
+        self.bytes_sent_without_drop = (self.world - 1) * (4 * int(blk.rows) + 12 * int(blk.nnz))
 
     def _pack(self, src, runs_key: int):
         torch = self.torch
@@ -461,7 +463,7 @@ def bench_main(args):
     t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     t = _all_reduce(t, op=dist.ReduceOp.MAX)
     sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.exchange.bytes_sent_per_run,
-                         st["bytes_algorithmic"]], dtype=torch.float64, device="cuda")
+                         st["bytes_algorithmic"], op.exchange.bytes_sent_without_drop], dtype=torch.float64, device="cuda")
     sums = _all_reduce(sums)
     drop = torch.tensor([1.0 - float(np.mean(op.bitmap))], dtype=torch.float64, device="cuda")
     drop = _all_reduce(drop)
@@ -469,7 +471,7 @@ def bench_main(args):
     mult_ms = _all_reduce(mult_ms, op=dist.ReduceOp.MAX)
     if rank == 0:
         ms_per_step = float(t.item()) * 1e3 / args.steps
-        nprod, nnz_c, nnz_a, nnz_b_local, sent, b_alg = (float(x) for x in sums.tolist())
+        nprod, nnz_c, nnz_a, nnz_b_local, sent, b_alg, sent_all = (float(x) for x in sums.tolist())
         out = {
             "metric": "SpGEMM GFLOP/s (useful flops, 2*nprod/t) C=A*A fp64",
             "value": 2.0 * nprod / (ms_per_step * 1e-3) / 1e9, "unit": "GFLOP/s", "n_gpus": world,
@@ -479,7 +481,7 @@ def bench_main(args):
             "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": int(nprod), "nnz_c": int(nnz_c),
                        "impl": args.impl, "n_sections": 512, "partition": getattr(args, "partition", "naive"),
                        "parallelism": f"{world} GPUs, A by row blocks, B row sections by all-to-all (RCCL)"},
-            "exchange": {"bytes_sent_all_ranks_per_step": int(sent), "b_entries_resident_all_ranks": int(nnz_b_local),
+            "exchange": {"bytes_sent_all_ranks_per_step": int(sent), "bytes_if_every_section_were_sent": int(sent_all), "b_entries_resident_all_ranks": int(nnz_b_local),
                          "mean_section_drop_fraction": float(drop.item()) / world},
             "whole_multiply": {"algorithmic_bytes_all_ranks": int(b_alg),
                                "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9,
