@@ -205,6 +205,15 @@ int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uint32_t *keep
                       uint64_t n_keep_rows, const uint32_t *col_new_id, uint64_t new_cols,
                       int sort_rows, spgemm_mat **out);
 
+/* The matrix M with its columns renamed by d_new_id (device array of M.cols entries, a bijection
+ * onto [0, new_cols)) and every row sorted by the new ids.  Used to apply the column shuffle
+ * (partition::Shuffle B_shuffle, reference src/main.cpp:131,216-217) to the RESULT of a multiply
+ * instead of to B: the entries and their values are bit for bit those of multiplying with a
+ * relabelled B (every entry still gets its products in the same order), while B keeps the
+ * locality the kernels live on.  *out is owned by the library. */
+int spgemm_mat_relabel_columns(spgemm_ctx *ctx, const spgemm_mat *M, const uint32_t *d_new_id,
+                               uint64_t new_cols, spgemm_mat **out);
+
 /* ---- B exchange helpers: replace BlockedCSRMatrix::filter + the receive-side rebuild
  *      (include/matrix_impl.hpp:507-534, :480-485) for a B that is cut into n_sections row
  *      sections of height rows/n_sections (last one takes the remainder, :628-639).
@@ -235,6 +244,9 @@ int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
 int spgemm_buffer_alloc(spgemm_ctx *ctx, size_t bytes, void **d_ptr);
 int spgemm_buffer_free(spgemm_ctx *ctx, void *d_ptr);
 int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, const void *d_src, size_t bytes);
+/* Host bytes into a device buffer of the context (set-up data such as a column permutation;
+ * returns when the copy is done). */
+int spgemm_buffer_upload(spgemm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -25,9 +25,9 @@ EXPORTED_SYMBOLS = [
     "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
     "spgemm_section_bitmap",
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
-    "spgemm_shuffle_random", "spgemm_shuffle_iterative", "spgemm_mat_select",
+    "spgemm_shuffle_random", "spgemm_shuffle_iterative", "spgemm_mat_select", "spgemm_mat_relabel_columns",
     "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr",
-    "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy",
+    "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy", "spgemm_buffer_upload",
 ]
 
 
@@ -113,6 +113,7 @@ def load() -> ctypes.CDLL:
         "spgemm_row_nprod": (i32, [vp, vp, vp, vp]),
         "spgemm_shuffle_random": (i32, [u32, u64, vp]),
         "spgemm_shuffle_iterative": (i32, [vp, vp, u32, vp, vp, vp]),
+        "spgemm_mat_relabel_columns": (i32, [vp, vp, vp, u64, pp]),
         "spgemm_mat_select": (i32, [vp, vp, vp, u64, vp, u64, i32, pp]),
         "spgemm_section_nnz": (i32, [vp, vp, u32, u64, u64, vp]),
         "spgemm_pack_sections": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, vp, ctypes.POINTER(u64),
@@ -331,6 +332,14 @@ class Context:
         h = ctypes.c_void_p()
         _check(load().spgemm_mat_select(self.handle, M.handle, _np_ptr(kr), 0 if kr is None else len(kr),
                                         _np_ptr(cn), new_cols, int(sort_rows), ctypes.byref(h)))
+        return DeviceCsr(self, h.value)
+
+    def relabel_columns(self, M: DeviceCsr, d_new_id: int, new_cols: int) -> DeviceCsr:
+        """M with column c renamed to new_id[c] (a device array given by its address, a bijection
+        onto [0, new_cols)) and the rows sorted by the new ids."""
+        h = ctypes.c_void_p()
+        _check(load().spgemm_mat_relabel_columns(self.handle, M.handle, ctypes.c_void_p(d_new_id), int(new_cols),
+                                                 ctypes.byref(h)))
         return DeviceCsr(self, h.value)
 
     # -- B exchange helpers -------------------------------------------------------------------------

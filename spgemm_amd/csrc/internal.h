@@ -8,4 +8,10 @@ extern "C" {
 int spgemm_internal_stream(spgemm_ctx *ctx, hipStream_t *stream);
 // records the message returned by spgemm_last_error() on this thread and returns `code`
 int spgemm_internal_fail(int code, const char *message);
+// a new matrix owned by the library, its three arrays taken from the context's buffer pool and
+// left uninitialised (freed with spgemm_mat_free)
+int spgemm_internal_alloc_mat(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz, spgemm_mat **out);
+// a block from the context's buffer pool / back to it (the stream must have drained the block's users)
+int spgemm_internal_pool_alloc(spgemm_ctx *ctx, size_t bytes, void **p, size_t *got);
+void spgemm_internal_pool_release(spgemm_ctx *ctx, void *p, size_t got);
 }

@@ -384,6 +384,32 @@ extern "C" int spgemm_internal_stream(spgemm_ctx *ctx, hipStream_t *stream) {
 
 extern "C" int spgemm_internal_fail(int code, const char *message) { return fail(code, "%s", message); }
 
+extern "C" int spgemm_internal_alloc_mat(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz, spgemm_mat **out) {
+  if (!ctx || !out) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  TRY(set_device(ctx));
+  spgemm_mat *m = new (std::nothrow) spgemm_mat();
+  if (!m) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
+  m->rows = rows; m->cols = cols; m->nnz = nnz; m->owns = true; m->device = ctx->device;
+  int rc = pool_alloc(ctx, (rows + 1) * 8, (void **)&m->d_ptr, &m->bytes_ptr);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 4, (void **)&m->d_col, &m->bytes_col);
+  if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 8, (void **)&m->d_val, &m->bytes_val);
+  if (rc != SPGEMM_OK) {
+    pool_release(ctx, m->d_ptr, m->bytes_ptr);
+    pool_release(ctx, m->d_col, m->bytes_col);
+    pool_release(ctx, m->d_val, m->bytes_val);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_internal_pool_alloc(spgemm_ctx *ctx, size_t bytes, void **p, size_t *got) {
+  return pool_alloc(ctx, bytes, p, got);
+}
+extern "C" void spgemm_internal_pool_release(spgemm_ctx *ctx, void *p, size_t got) { pool_release(ctx, p, got); }
+
 extern "C" int spgemm_synchronize(spgemm_ctx *ctx) {
   if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
   TRY(set_device(ctx));
@@ -1427,6 +1453,15 @@ extern "C" int spgemm_buffer_free(spgemm_ctx *ctx, void *d_ptr) {
       return SPGEMM_OK;
     }
   return fail(SPGEMM_ERR_INVALID, "pointer was not allocated by spgemm_buffer_alloc on this context");
+}
+
+extern "C" int spgemm_buffer_upload(spgemm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  if (!ctx || (bytes && (!d_dst || !h_src))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (!bytes) return SPGEMM_OK;
+  TRY(set_device(ctx));
+  HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
 }
 
 extern "C" int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, const void *d_src, size_t bytes) {

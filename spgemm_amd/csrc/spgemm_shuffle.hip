@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "internal.h"
 
@@ -87,6 +89,19 @@ __global__ void __launch_bounds__(256) k_rank(uint32_t n, const uint32_t *__rest
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[sorted_id[i]] = i;
 }
+
+// new column id of every entry (no entry may be dropped here: every id must be a column of the result)
+__global__ void __launch_bounds__(256)
+    k_relabel(uint64_t nnz, const uint32_t *__restrict__ col, const uint32_t *__restrict__ new_id, uint32_t *__restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) out[i] = new_id[col[i]];
+}
+
+// row pointer relative to the first entry of a range of rows, as the 32-bit offsets the segmented sort takes
+struct RelativeOffset {
+  uint64_t base;
+  __host__ __device__ unsigned int operator()(uint64_t v) const { return (unsigned int)(v - base); }
+};
 
 inline uint32_t blocks_for(uint64_t n, uint32_t per_block = 256) { return (uint32_t)((n + per_block - 1) / per_block); }
 
@@ -190,5 +205,118 @@ extern "C" int spgemm_shuffle_iterative(spgemm_ctx *ctx, const spgemm_mat *C, ui
   SH_HIP(hipStreamSynchronize(st));
   for (uint32_t r = 0; r < rows; ++r) row_shuffle[pr[r]] = r;
   for (uint32_t c = 0; c < cols; ++c) col_shuffle[pc[c]] = c;
+  return SPGEMM_OK;
+}
+
+// Columns of M renamed by new_id (a device array of M.cols entries, a bijection onto [0, new_cols))
+// and every row sorted by its new column ids, values moving with their columns.  A permutation
+// of the columns commutes with the multiply: (A * B) with the columns of the RESULT renamed equals
+// A * (B with its columns renamed), entry for entry and bit for bit, because every output entry
+// still receives the same products in the same order.  Renaming the result leaves B, and with it
+// the locality of the multiply, untouched.
+extern "C" int spgemm_mat_relabel_columns(spgemm_ctx *ctx, const spgemm_mat *M, const uint32_t *d_new_id,
+                                          uint64_t new_cols, spgemm_mat **out) {
+  if (!ctx || !M || !d_new_id || !out) return spgemm_internal_fail(SPGEMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  hipStream_t st;
+  int rc = spgemm_internal_stream(ctx, &st);
+  if (rc != SPGEMM_OK) return rc;
+  uint64_t rows = 0, cols = 0, nnz = 0;
+  rc = spgemm_mat_info(M, &rows, &cols, &nnz);
+  if (rc != SPGEMM_OK) return rc;
+  if (new_cols == 0 || new_cols > 0xFFFFFFFFull) return spgemm_internal_fail(SPGEMM_ERR_INVALID, "new_cols out of range");
+  const uint64_t *m_ptr = nullptr;
+  const uint32_t *m_col = nullptr;
+  const double *m_val = nullptr;
+  rc = spgemm_mat_device_ptrs(M, &m_ptr, &m_col, &m_val);
+  if (rc != SPGEMM_OK) return rc;
+  spgemm_mat *R = nullptr;
+  rc = spgemm_internal_alloc_mat(ctx, rows, new_cols, nnz, &R);
+  if (rc != SPGEMM_OK) return rc;
+  const uint64_t *cr_ptr = nullptr;
+  const uint32_t *cr_col = nullptr;
+  const double *cr_val = nullptr;
+  rc = spgemm_mat_device_ptrs(R, &cr_ptr, &cr_col, &cr_val);
+  if (rc != SPGEMM_OK) { spgemm_mat_free(ctx, R); return rc; }
+  uint64_t *r_ptr = const_cast<uint64_t *>(cr_ptr);
+  uint32_t *r_col = const_cast<uint32_t *>(cr_col);
+  double *r_val = const_cast<double *>(cr_val);
+  void *keys = nullptr, *tmp = nullptr;
+  size_t keys_got = 0, tmp_got = 0;
+  auto fail_out = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    if (keys) spgemm_internal_pool_release(ctx, keys, keys_got);
+    if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+    spgemm_mat_free(ctx, R);
+    return code;
+  };
+#define RL_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      std::string m_ = std::string(#expr) + " failed: " + hipGetErrorString(e_);                  \
+      return fail_out(spgemm_internal_fail(SPGEMM_ERR_HIP, m_.c_str()));                          \
+    }                                                                                             \
+  } while (0)
+  RL_HIP(hipMemcpyAsync(r_ptr, m_ptr, (rows + 1) * 8, hipMemcpyDeviceToDevice, st));
+  if (nnz) {
+    rc = spgemm_internal_pool_alloc(ctx, nnz * 4, &keys, &keys_got);
+    if (rc != SPGEMM_OK) return fail_out(rc);
+    hipLaunchKernelGGL(k_relabel, dim3(blocks_for(nnz)), dim3(256), 0, st, nnz, m_col, d_new_id, static_cast<uint32_t *>(keys));
+    RL_HIP(hipGetLastError());
+    unsigned int end_bit = 1;
+    while (end_bit < 32 && (new_cols - 1) >> end_bit) ++end_bit;
+    // the segmented sort counts entries in 32 bits: ranges of rows of fewer than 2^31 entries each
+    std::vector<uint64_t> cuts{0, rows};
+    if (nnz >= (1ull << 31)) {
+      std::vector<uint64_t> h_ptr(rows + 1);
+      RL_HIP(hipMemcpyAsync(h_ptr.data(), m_ptr, (rows + 1) * 8, hipMemcpyDeviceToHost, st));
+      RL_HIP(hipStreamSynchronize(st));
+      cuts.assign(1, 0);
+      uint64_t r0 = 0;
+      while (r0 < rows) {
+        uint64_t r1 = r0 + 1; // a row of 2^31 entries or more cannot exist: fewer than 2^32 columns... but guard anyway
+        while (r1 < rows && h_ptr[r1 + 1] - h_ptr[r0] < (1ull << 31)) ++r1;
+        if (h_ptr[r1] - h_ptr[r0] >= (1ull << 31)) return fail_out(spgemm_internal_fail(SPGEMM_ERR_UNSUPPORTED, "a row of 2^31 entries or more"));
+        cuts.push_back(r1);
+        r0 = r1;
+      }
+      // the bases of the ranges are needed below
+      std::vector<uint64_t> bases;
+      for (size_t i = 0; i + 1 < cuts.size(); ++i) bases.push_back(h_ptr[cuts[i]]);
+      bases.push_back(nnz);
+      for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        const uint64_t base = bases[i], cnt = bases[i + 1] - base, segs = cuts[i + 1] - cuts[i];
+        if (!cnt) continue;
+        auto offs = rocprim::make_transform_iterator(m_ptr + cuts[i], RelativeOffset{base});
+        size_t need = 0;
+        RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, static_cast<uint32_t *>(keys) + base, r_col + base, m_val + base,
+                                                   r_val + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
+        if (need > tmp_got) {
+          RL_HIP(hipStreamSynchronize(st));
+          if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+          tmp = nullptr;
+          rc = spgemm_internal_pool_alloc(ctx, need, &tmp, &tmp_got);
+          if (rc != SPGEMM_OK) return fail_out(rc);
+        }
+        RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, static_cast<uint32_t *>(keys) + base, r_col + base, m_val + base,
+                                                   r_val + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
+      }
+    } else {
+      auto offs = rocprim::make_transform_iterator(m_ptr, RelativeOffset{0});
+      size_t need = 0;
+      RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, static_cast<uint32_t *>(keys), r_col, m_val, r_val, (unsigned int)nnz,
+                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
+      rc = spgemm_internal_pool_alloc(ctx, need ? need : 8, &tmp, &tmp_got);
+      if (rc != SPGEMM_OK) return fail_out(rc);
+      RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, static_cast<uint32_t *>(keys), r_col, m_val, r_val, (unsigned int)nnz,
+                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
+    }
+  }
+  RL_HIP(hipStreamSynchronize(st));
+#undef RL_HIP
+  if (keys) spgemm_internal_pool_release(ctx, keys, keys_got);
+  if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+  *out = R;
   return SPGEMM_OK;
 }

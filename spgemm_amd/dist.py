@@ -117,7 +117,10 @@ class RankOperands:
 
 
 def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partitions: Sequence[Partition],
-                        A_shuffle: np.ndarray, B_shuffle: np.ndarray, n_sections: int) -> RankOperands:
+                        A_shuffle: np.ndarray, B_shuffle: np.ndarray, n_sections: int,
+                        relabel_b: bool = True) -> RankOperands:
+    """relabel_b=False leaves the columns of the B block as they are: the caller renames the columns
+    of the RESULT instead (same entries, same values; B keeps its locality)."""
     p = partitions[rank]
     A_part = select_rows(A, A_shuffle[p[0]:p[1]])
     sb = section_bounds(B.rows, n_sections)
@@ -126,7 +129,7 @@ def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partition
     blk = select_rows(B, np.arange(r0, r1, dtype=np.int64))
     inv = np.empty(B.cols, dtype=np.int64)
     inv[B_shuffle] = np.arange(B.cols, dtype=np.int64)
-    if not np.array_equal(B_shuffle, np.arange(B.cols)):
+    if relabel_b and not np.array_equal(B_shuffle, np.arange(B.cols)):
         blk = relabel_cols(blk, inv)
     return RankOperands(A_part, blk, r0, B.rows, B.cols)
 
@@ -336,8 +339,16 @@ class DistSpgemm:
             self.partitions = capi.partition_balanced(row_products(A, B)[self.A_shuffle], B.cols, self.world)
         else:
             raise ValueError("partition must be naive or balanced")
+        # A column shuffle is applied to the result of the multiply, not to B (a permutation of the
+        # columns commutes with the product, bit for bit): B keeps the column locality the window
+        # kernels live on.  new_id[c] = position of original column c.
+        self.col_new_id = None
+        if not np.array_equal(self.B_shuffle, np.arange(B.cols)):
+            inv = np.empty(B.cols, dtype=np.int32)
+            inv[self.B_shuffle] = np.arange(B.cols, dtype=np.int32)
+            self.col_new_id = torch.from_numpy(inv).to(self.device)
         self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
-                                       n_sections)
+                                       n_sections, relabel_b=False)
         ap = self.ops.A_part
         self.dA = self.ctx.from_host(ap.rows, ap.cols, ap.row_ptr, ap.col_idx, ap.val)
         if impl == "baseline":
@@ -365,6 +376,10 @@ class DistSpgemm:
             self.C = self.ctx.multiply(self.dA, dB)   # returns after the stream has drained
             self.last_stats = self.ctx.stats()
             dB.free()
+            if self.col_new_id is not None:
+                shuffled = self.ctx.relabel_columns(self.C, self.col_new_id.data_ptr(), self.ops.n_cols)
+                self.C.free()
+                self.C = shuffled
         return self.C
 
     def result(self) -> HostCsr:

@@ -89,9 +89,10 @@ struct HipOptions {
 // Row-wise Gustavson on the GPU for one rank.
 //
 //  * part_A: rows keep_rows of A (the reference loads them the same way, src/main.cpp:213-217);
-//  * B: this rank owns the row sections [rank*N/P, (rank+1)*N/P) of B with ALL columns, relabelled
-//    so that column p stands for original column col_order[p] (the whole B_shuffle; the reference
-//    passes only its slice, keep_cols, because it cuts B by columns);
+//  * B: this rank owns the row sections [rank*N/P, (rank+1)*N/P) of B with ALL columns; the column
+//    order col_order (the whole B_shuffle: column p of the result stands for original column
+//    col_order[p]; the reference passes only its slice, keep_cols, because it cuts B by columns) is
+//    applied to the result;
 //  * gemm(): pulls the sections the bitmap marks from every rank, in ascending order, straight into
 //    the col_idx/val arrays of a full-height local B, then one multiply gives the rank's rows of C
 //    (local row ids, shuffled-global column ids: exactly what the reference's C_<rank>.mtx holds).
@@ -102,6 +103,7 @@ class HipSpgemm : public MatrixMultiplication {
   spgemm_mat *part_A = nullptr;
   spgemm_mat *block_B = nullptr; // my row sections
   spgemm_mat *C = nullptr;
+  void *d_col_new_id = nullptr; // device: new column id of every original column (null: identity)
   uint64_t b_first_row = 0, b_rows_total = 0, b_cols = 0;
   std::vector<uint64_t> sec_nnz;       // entries of each of MY sections (index: global section id)
   std::vector<uint64_t> sec_blob_size; // reference blob size of each of my sections
@@ -143,10 +145,23 @@ public:
     b_first_row = r0;
     std::vector<midx_t> rows_keep;
     for (uint64_t r = r0; r < r1; ++r) rows_keep.push_back((midx_t)r);
-    // keep_cols semantics of the loader: original column c gets the index of c in col_order
-    matrix::ManagedCSRMatrix<> hB(tB, false, &rows_keep, col_order);
-    sort_rows(hB);
+    // The column order is applied to the RESULT of every multiply (spgemm_mat_relabel_columns), not
+    // to B: a permutation of the columns commutes with the product bit for bit, and B keeps the
+    // column locality the kernels live on.  new id of original column c = position of c in col_order
+    // (the keep_cols semantics of the loader).
+    matrix::ManagedCSRMatrix<> hB(tB, false, &rows_keep, nullptr);
     upload(ctx, hB, &block_B);
+    if (col_order) {
+      bool identity = col_order->size() == b_cols;
+      for (size_t p = 0; identity && p < col_order->size(); ++p) identity = (*col_order)[p] == p;
+      if (!identity) {
+        if (col_order->size() != b_cols) throw std::runtime_error("the column order must hold every column of B once");
+        std::vector<uint32_t> new_id(b_cols);
+        for (size_t p = 0; p < col_order->size(); ++p) new_id[(*col_order)[p]] = (uint32_t)p;
+        HOST_TRY(spgemm_buffer_alloc(ctx, (size_t)b_cols * 4, &d_col_new_id));
+        HOST_TRY(spgemm_buffer_upload(ctx, d_col_new_id, new_id.data(), (size_t)b_cols * 4));
+      }
+    }
     sec_nnz.assign(opt.n_sections, 0);
     sec_blob_size.assign(opt.n_sections, 0);
     for (uint32_t s = sec_lo(rank); s < sec_lo(rank + 1); ++s) {
@@ -161,29 +176,10 @@ public:
   }
 
   ~HipSpgemm() override {
+    if (d_col_new_id) spgemm_buffer_free(ctx, d_col_new_id);
     spgemm_mat_free(ctx, C);
     spgemm_mat_free(ctx, part_A);
     spgemm_mat_free(ctx, block_B);
-  }
-
-  // After relabelling, rows are put back in ascending column order.
-  static void sort_rows(matrix::ManagedCSRMatrix<> &m) {
-    std::vector<std::pair<midx_t, double>> tmp;
-    for (midx_t r = 0; r < m.height; ++r) {
-      midx_t a = m.row_ptr[r], b = m.row_ptr[r + 1];
-      if (std::is_sorted(m.col_idx + a, m.col_idx + b)) continue;
-      tmp.clear();
-      for (midx_t j = a; j < b; ++j) {
-        double v;
-        std::memcpy(&v, reinterpret_cast<std::byte *>(m.values) + (size_t)j * 8, 8);
-        tmp.push_back({m.col_idx[j], v});
-      }
-      std::stable_sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
-      for (midx_t j = a; j < b; ++j) {
-        m.col_idx[j] = tmp[j - a].first;
-        std::memcpy(reinterpret_cast<std::byte *>(m.values) + (size_t)j * 8, &tmp[j - a].second, 8);
-      }
-    }
   }
 
   // Size of my B block in the reference's blocked serialization (header + section blobs).
@@ -285,6 +281,12 @@ public:
     measure_point(rank, measure::deserialize, measure::MeasurementEvent::END);
     measure_point(rank, measure::mult, measure::MeasurementEvent::START);
     HOST_TRY(spgemm_multiply(ctx, part_A, B_local, &C));
+    if (d_col_new_id) {
+      spgemm_mat *shuffled = nullptr;
+      HOST_TRY(spgemm_mat_relabel_columns(ctx, C, (const uint32_t *)d_col_new_id, b_cols, &shuffled));
+      spgemm_mat_free(ctx, C);
+      C = shuffled;
+    }
     measure_point(rank, measure::mult, measure::MeasurementEvent::END);
     spgemm_stats st;
     HOST_TRY(spgemm_get_stats(ctx, &st));

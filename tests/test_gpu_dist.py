@@ -224,3 +224,27 @@ def test_dist_operator_with_iterative_shuffling(pg):
     ers, ecs, _ = orc.iterative_shuffle(E, 10)
     assert np.array_equal(op.A_shuffle, ers) and np.array_equal(op.B_shuffle, ecs)
     op.close()
+
+
+def test_relabel_columns_matches_numpy():
+    """Columns renamed by a permutation and rows re-sorted on the device = the same on the host."""
+    import torch
+    ctx = capi.Context(0)
+    A = hostcsr.rmat(11, 6, seed=9)
+    d = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    perm = capi.shuffle_random(A.cols, 12)                       # position -> original column
+    new_id = np.empty(A.cols, dtype=np.int64)
+    new_id[perm] = np.arange(A.cols)                             # original column -> position
+    t = torch.from_numpy(new_id.astype(np.int32)).cuda()
+    r = ctx.relabel_columns(d, t.data_ptr(), A.cols)
+    rp, ci, v = r.to_host()
+    want = sd.relabel_cols(A, new_id)
+    assert np.array_equal(rp, want.row_ptr) and np.array_equal(ci, want.col_idx) and np.array_equal(v, want.val)
+    E = hostcsr.HostCsr.from_coo(5, 7, [], [], [])               # no entries at all
+    de = ctx.from_host(E.rows, E.cols, E.row_ptr, E.col_idx, E.val)
+    t7 = torch.arange(7, dtype=torch.int32).cuda()
+    re_ = ctx.relabel_columns(de, t7.data_ptr(), 7)
+    assert re_.info() == (5, 7, 0)
+    for h in (r, d, re_, de):
+        h.free()
+    ctx.close()
