@@ -187,6 +187,9 @@ def main():
                          "or random row/column shuffle + bitmap")
     ap.add_argument("--partition", default="naive", choices=["naive", "balanced"],
                     help="row blocks of the distributed variant: equal row counts, or equal product counts")
+    ap.add_argument("--stages", type=int, default=1,
+                    help="distributed variant: > 1 cuts a rank's rows into that many blocks and overlaps the "
+                         "exchange of the next block with the multiply of the current one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (spgemm_set_option), e.g. --opt row_groups=0")

@@ -174,7 +174,9 @@ class SectionExchange:
     gathered bitmaps and the global per-section entry counts, the split sizes of the collective.
     `run()` returns (row_ptr int64[n+1], col int32[nnz], val float64[nnz]) of the local B."""
 
-    def __init__(self, ops: RankOperands, n_sections: int, bitmaps: np.ndarray, device, group=None):
+    def __init__(self, ops: RankOperands, n_sections: int, bitmaps: np.ndarray, device, group=None, share=None):
+        """share: another SectionExchange over the same B block, whose device copies of the block
+        are used instead of making new ones (several exchanges with different bitmaps)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -185,9 +187,12 @@ class SectionExchange:
         self.sb = section_bounds(ops.n, n_sections)
         self.ob = section_owner_bounds(n_sections, self.world)
         blk = ops.B_block
-        self.row_len = torch.from_numpy(np.diff(blk.row_ptr.astype(np.int64)).astype(np.int32)).to(device)
-        self.col = torch.from_numpy(blk.col_idx.view(np.int32).copy()).to(device)
-        self.val = torch.from_numpy(blk.val.copy()).to(device)
+        if share is not None:
+            self.row_len, self.col, self.val = share.row_len, share.col, share.val
+        else:
+            self.row_len = torch.from_numpy(np.diff(blk.row_ptr.astype(np.int64)).astype(np.int32)).to(device)
+            self.col = torch.from_numpy(blk.col_idx.view(np.int32).copy()).to(device)
+            self.val = torch.from_numpy(blk.val.copy()).to(device)
         # entries per section, globally: every section is owned by exactly one rank
         my_lo, my_hi = int(self.ob[self.rank]), int(self.ob[self.rank + 1])
         rp = blk.row_ptr.astype(np.int64)
@@ -292,7 +297,12 @@ class DistSpgemm:
 
     def __init__(self, A: HostCsr, B: Optional[HostCsr], impl: str = "drop", n_sections: int = 512, seed: int = 1,
                  partition: str = "naive", device_index: Optional[int] = None, group=None,
-                 shuffling: Optional[str] = None, shuffle_iterations: int = 20):
+                 shuffling: Optional[str] = None, shuffle_iterations: int = 20, stages: int = 1):
+        """stages > 1: the pipelined schedule.  The rank's rows are cut into `stages` blocks, each with
+        its own section bitmap and exchange; the exchange of block s + 1 runs on a second stream
+        while block s is multiplied (the overlap the reference's ring gets from Isend/Irecv around
+        mult_step, src/mults/drop_parallel.cpp:79-114).  Every row of C is still computed by one
+        full-width multiply, so the result is the same, bit for bit."""
         import torch
         import torch.distributed as dist
         from . import capi
@@ -350,46 +360,107 @@ class DistSpgemm:
         self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
                                        n_sections, relabel_b=False)
         ap = self.ops.A_part
-        self.dA = self.ctx.from_host(ap.rows, ap.cols, ap.row_ptr, ap.col_idx, ap.val)
-        if impl == "baseline":
-            bits = np.ones(n_sections, dtype=bool)
-        else:
-            bits = self.ctx.section_bitmap(self.dA, n_sections)   # device-built, reference rule
-        self.bitmap = bits
-        self.bitmaps = gather_bitmaps(bits, self.device, group)
-        self.exchange = SectionExchange(self.ops, n_sections, self.bitmaps, self.device, group)
+        if stages < 1:
+            raise ValueError("stages must be at least 1")
+        self.n_stages = int(stages)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.n_stages > 1 else None
+        # every rank cuts its rows the same way (equal shares), so that all ranks issue the same
+        # sequence of collectives
+        cuts = [(ap.rows * s) // self.n_stages for s in range(self.n_stages + 1)]
+        self.stage_rows = list(zip(cuts[:-1], cuts[1:]))
+        self.dA_stage, self.bitmap_stage, self.exchange_stage = [], [], []
+        for r0, r1 in self.stage_rows:
+            sub = ap if self.n_stages == 1 else select_rows(ap, np.arange(r0, r1, dtype=np.int64))
+            dA = self.ctx.from_host(sub.rows, sub.cols, sub.row_ptr, sub.col_idx, sub.val)
+            if impl == "baseline":
+                bits = np.ones(n_sections, dtype=bool)
+            else:
+                bits = self.ctx.section_bitmap(dA, n_sections)   # device-built, reference rule
+            bitmaps = gather_bitmaps(bits, self.device, group)
+            share = self.exchange_stage[0] if self.exchange_stage else None
+            self.dA_stage.append(dA)
+            self.bitmap_stage.append(bits)
+            self.exchange_stage.append(SectionExchange(self.ops, n_sections, bitmaps, self.device, group, share=share))
+        self.dA = self.dA_stage[0]
+        self.bitmap = np.logical_or.reduce(self.bitmap_stage)      # sections this rank needs at all
+        self.bitmaps = self.exchange_stage[0].bitmaps
+        self.exchange = self.exchange_stage[0]
+        self.bytes_sent_per_run = sum(e.bytes_sent_per_run for e in self.exchange_stage)
+        self.bytes_sent_without_drop = sum(e.bytes_sent_without_drop for e in self.exchange_stage)
+        self.C_stage = []
         self.C = None
-        self._keep = None
+
+    def _multiply_stage(self, s, received):
+        row_ptr, col, val = received
+        dB = self.ctx.wrap_device(self.ops.n, self.ops.n_cols, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(),
+                                  val.data_ptr(), validate=False, keepalive=(row_ptr, col, val))
+        C = self.ctx.multiply(self.dA_stage[s], dB)   # returns after the stream has drained
+        st = self.ctx.stats()
+        dB.free()
+        if self.col_new_id is not None:
+            shuffled = self.ctx.relabel_columns(C, self.col_new_id.data_ptr(), self.ops.n_cols)
+            C.free()
+            C = shuffled
+        return C, st
 
     def gemm(self):
-        """One timed run: exchange of the needed B sections + the local multiply."""
+        """One timed run: exchange of the needed B sections + the local multiply (per stage)."""
         torch = self.torch
-        if self.C is not None:
-            self.C.free()
-            self.C = None
+        for C in self.C_stage:
+            C.free()
+        self.C_stage, self.C = [], None
+        stats = []
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
-            row_ptr, col, val = self.exchange.run()
-            n = self.ops.n
-            dB = self.ctx.wrap_device(n, self.ops.n_cols, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(),
-                                      val.data_ptr(), validate=False, keepalive=(row_ptr, col, val))
-            self.C = self.ctx.multiply(self.dA, dB)   # returns after the stream has drained
-            self.last_stats = self.ctx.stats()
-            dB.free()
-            if self.col_new_id is not None:
-                shuffled = self.ctx.relabel_columns(self.C, self.col_new_id.data_ptr(), self.ops.n_cols)
-                self.C.free()
-                self.C = shuffled
+        if self.n_stages == 1:
+            with torch.cuda.stream(self.stream):
+                C, st = self._multiply_stage(0, self.exchange_stage[0].run())
+            self.C_stage, stats = [C], [st]
+        else:
+            self.comm_stream.wait_stream(self.stream)
+            with torch.cuda.stream(self.comm_stream):
+                nxt = self.exchange_stage[0].run()
+                ready = torch.cuda.Event()
+                ready.record(self.comm_stream)
+            for s in range(self.n_stages):
+                cur, cur_ready = nxt, ready
+                if s + 1 < self.n_stages:  # queued before the multiply below blocks the host
+                    with torch.cuda.stream(self.comm_stream):
+                        nxt = self.exchange_stage[s + 1].run()
+                        ready = torch.cuda.Event()
+                        ready.record(self.comm_stream)
+                self.stream.wait_event(cur_ready)
+                with torch.cuda.stream(self.stream):
+                    C, st = self._multiply_stage(s, cur)
+                self.C_stage.append(C)
+                stats.append(st)
+                del cur
+            self.comm_stream.synchronize()
+        self.C = self.C_stage[0]
+        self.last_stats = dict(stats[0])
+        for st in stats[1:]:
+            for k, v in st.items():
+                if k in ("nnz_b", "temp_bytes"):  # not additive over the stages
+                    self.last_stats[k] = max(self.last_stats[k], v)
+                elif isinstance(v, (int, float)):
+                    self.last_stats[k] = self.last_stats[k] + v
         return self.C
 
     def result(self) -> HostCsr:
-        rp, ci, v = self.C.to_host()
+        parts = [C.to_host() for C in self.C_stage]
+        if len(parts) == 1:
+            rp, ci, v = parts[0]
+        else:
+            offs = np.cumsum([0] + [int(p[0][-1]) for p in parts]).astype(np.uint64)
+            rp = np.concatenate([parts[0][0]] + [p[0][1:] + offs[i + 1] for i, p in enumerate(parts[1:])])
+            ci = np.concatenate([p[1] for p in parts])
+            v = np.concatenate([p[2] for p in parts])
         return HostCsr(self.ops.A_part.rows, self.ops.n_cols, rp, ci, v)
 
     def close(self):
-        if self.C is not None:
-            self.C.free()
-        self.dA.free()
+        for C in self.C_stage:
+            C.free()
+        for dA in self.dA_stage:
+            dA.free()
         self.ctx.close()
 
 
@@ -433,7 +504,7 @@ def bench_main(args):
         dist.init_process_group(backend)
     A, name = bench_mod.make_workload(args)
     op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local,
-                    partition=getattr(args, "partition", "naive"))
+                    partition=getattr(args, "partition", "naive"), stages=getattr(args, "stages", 1))
     op.ctx.set_option("profile_launches", 1)  # HIP events around every launch, on the operator's stream
     for o in getattr(args, "opt", []):
         opt_name, opt_value = o.split("=")
@@ -477,8 +548,8 @@ def bench_main(args):
                         "scope": "rank 0's launch, one GPU's peak"}
     t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     t = _all_reduce(t, op=dist.ReduceOp.MAX)
-    sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.exchange.bytes_sent_per_run,
-                         st["bytes_algorithmic"], op.exchange.bytes_sent_without_drop], dtype=torch.float64, device="cuda")
+    sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.bytes_sent_per_run,
+                         st["bytes_algorithmic"], op.bytes_sent_without_drop], dtype=torch.float64, device="cuda")
     sums = _all_reduce(sums)
     drop = torch.tensor([1.0 - float(np.mean(op.bitmap))], dtype=torch.float64, device="cuda")
     drop = _all_reduce(drop)
@@ -495,6 +566,7 @@ def bench_main(args):
             "data": "synthetic" if args.workload != "mtx" else "file",
             "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": int(nprod), "nnz_c": int(nnz_c),
                        "impl": args.impl, "n_sections": 512, "partition": getattr(args, "partition", "naive"),
+                       "stages": getattr(args, "stages", 1),
                        "parallelism": f"{world} GPUs, A by row blocks, B row sections by all-to-all (RCCL)"},
             "exchange": {"bytes_sent_all_ranks_per_step": int(sent), "bytes_if_every_section_were_sent": int(sent_all), "b_entries_resident_all_ranks": int(nnz_b_local),
                          "mean_section_drop_fraction": float(drop.item()) / world},

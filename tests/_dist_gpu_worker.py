@@ -32,17 +32,20 @@ def main():
     for name, A, N in cases:
         E = orc.spgemm(to_o(A), to_o(A))
         sent = {}
-        for impl in ("baseline", "drop", "shuffle", "drop+balanced"):
+        for impl in ("baseline", "drop", "shuffle", "drop+balanced", "drop+stages", "shuffle+stages"):
             partition = "balanced" if impl.endswith("+balanced") else "naive"
+            stages = 3 if impl.endswith("+stages") else 1   # pipelined schedule: 3 blocks of rows per rank
+            variant = impl
             impl = impl.split("+")[0]
-            op = sd.DistSpgemm(A, None, impl=impl, n_sections=N, seed=7, device_index=0, partition=partition)
+            op = sd.DistSpgemm(A, None, impl=impl, n_sections=N, seed=7, device_index=0, partition=partition,
+                               stages=stages)
             op.gemm()
             op.gemm()
             C = op.result()
             ref = orc.distributed_reference(to_o(A), to_o(A), world, op.partitions, op.A_shuffle, op.B_shuffle,
                                             n_sections=N)
             orc.assert_same(to_o(C), ref[rank].C, rtol=0.0)
-            if impl != "baseline":
+            if impl != "baseline":  # with stages: the union of the blocks' bitmaps
                 assert np.array_equal(op.bitmap, ref[rank].bitmap), (name, impl, rank)
             gathered = [None] * world
             dist.all_gather_object(gathered, (C.row_ptr, C.col_idx, C.val))
@@ -51,9 +54,9 @@ def main():
                       for r in range(world)]
                 M = sd.merge_unshuffle(Cs, op.partitions, op.A_shuffle, op.B_shuffle, A.rows, A.cols)
                 orc.assert_same(to_o(M), E, rtol=0.0)
-            tot = torch.tensor([op.exchange.bytes_sent_per_run], dtype=torch.int64)
+            tot = torch.tensor([op.bytes_sent_per_run], dtype=torch.int64)
             dist.all_reduce(tot)
-            sent[impl if partition == "naive" else impl + "+balanced"] = int(tot.item())
+            sent[variant] = int(tot.item())
             op.close()
         assert sent["drop"] <= sent["baseline"], sent
         if rank == 0:
