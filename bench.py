@@ -88,11 +88,18 @@ def cpu_baseline(A, target_seconds=12.0):
     rows = int(min(A.rows, max(probe_rows, target_seconds * rate / prod_per_row)))
     start = (A.rows - rows) // 2
     sub = full.select_rows(np.arange(start, start + rows))
-    _, st = orc.spgemm(sub, full, with_stats=True, nthreads=cores)
-    gflops = 2.0 * st["nprod"] / st["seconds"] / 1e9
+    # repeated until about target_seconds of CPU work have been timed (the whole workload is short of it
+    # on a many-core host)
+    seconds, nprod, reps = 0.0, 0, 0
+    while reps == 0 or (seconds < 0.8 * target_seconds and reps < 32):
+        _, st = orc.spgemm(sub, full, with_stats=True, nthreads=cores)
+        seconds += st["seconds"]
+        nprod += st["nprod"]
+        reps += 1
+    gflops = 2.0 * nprod / seconds / 1e9
     return {"value": gflops, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"rows [{start}, {start + rows}) of A times all of A: {st['nprod']} products "
-                      f"in {st['seconds']:.2f} s (accumulate loop only, as the reference times it)"}
+            "sample": f"rows [{start}, {start + rows}) of A times all of A, {reps} time(s): {nprod} products "
+                      f"in {seconds:.2f} s (accumulate loop only, as the reference times it)"}
 
 
 def run_single(args):
