@@ -65,6 +65,29 @@ def row_products(A: HostCsr, B: HostCsr) -> np.ndarray:
     return w.astype(np.uint64)
 
 
+def product_rows_are_narrow(A: HostCsr, B: HostCsr, max_span: int = 65536) -> bool:
+    """True when most rows of A * B span at most max_span columns (column hull of the B rows a row
+    of A selects), i.e. when B has column locality that a relabelling of B would destroy.  Decides
+    where a column shuffle is applied: to the result (B untouched) or to B."""
+    if A.nnz == 0 or B.nnz == 0:
+        return False
+    rp = B.row_ptr.astype(np.int64)
+    has = rp[1:] > rp[:-1]
+    bmin = np.full(B.rows, np.iinfo(np.int64).max, dtype=np.int64)
+    bmax = np.full(B.rows, -1, dtype=np.int64)
+    ci = B.col_idx.astype(np.int64)
+    bmin[has] = np.minimum.reduceat(ci, rp[:-1][has])
+    bmax[has] = np.maximum.reduceat(ci, rp[:-1][has])
+    k = A.col_idx.astype(np.int64)
+    arp = A.row_ptr.astype(np.int64)
+    ahas = arp[1:] > arp[:-1]
+    lo = np.minimum.reduceat(bmin[k], arp[:-1][ahas])
+    hi = np.maximum.reduceat(bmax[k], arp[:-1][ahas])
+    span = hi - lo + 1
+    live = hi >= 0
+    return bool(live.any()) and float(np.mean(span[live] <= max_span)) >= 0.5
+
+
 def iterative_shuffles(ctx, A: HostCsr, B: HostCsr, iterations: int = 20) -> Tuple[np.ndarray, np.ndarray]:
     """The reference's `iterative` shuffling (src/main.cpp:151-152, src/partition.cpp:123-202): the
     pattern of C is computed here on the device (the reference reads C_sparsity.mtx)."""
@@ -297,7 +320,8 @@ class DistSpgemm:
 
     def __init__(self, A: HostCsr, B: Optional[HostCsr], impl: str = "drop", n_sections: int = 512, seed: int = 1,
                  partition: str = "naive", device_index: Optional[int] = None, group=None,
-                 shuffling: Optional[str] = None, shuffle_iterations: int = 20, stages: int = 1):
+                 shuffling: Optional[str] = None, shuffle_iterations: int = 20, stages: int = 1,
+                 relabel: Optional[str] = None):
         """stages > 1: the pipelined schedule.  The rank's rows are cut into `stages` blocks, each with
         its own section bitmap and exchange; the exchange of block s + 1 runs on a second stream
         while block s is multiplied (the overlap the reference's ring gets from Isend/Irecv around
@@ -352,13 +376,21 @@ class DistSpgemm:
         # A column shuffle is applied to the result of the multiply, not to B (a permutation of the
         # columns commutes with the product, bit for bit): B keeps the column locality the window
         # kernels live on.  new_id[c] = position of original column c.
+        # That pays when B has column locality to lose (rows of the product a few ten thousand
+        # columns wide: the window path); for a B without it (Erdos-Renyi, R-MAT) sorting the result
+        # costs more than it saves, and B is relabelled up front.  The rule reads the whole
+        # operands, so every rank decides the same (the exchanged sections carry the column ids).
         self.col_new_id = None
-        if not np.array_equal(self.B_shuffle, np.arange(B.cols)):
+        shuffled_cols = not np.array_equal(self.B_shuffle, np.arange(B.cols))
+        if relabel not in (None, "result", "b"):
+            raise ValueError("relabel must be None (decide from the operands), 'result' or 'b'")
+        self.late_relabel = shuffled_cols and (product_rows_are_narrow(A, B) if relabel is None else relabel == "result")
+        if self.late_relabel:
             inv = np.empty(B.cols, dtype=np.int32)
             inv[self.B_shuffle] = np.arange(B.cols, dtype=np.int32)
             self.col_new_id = torch.from_numpy(inv).to(self.device)
         self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
-                                       n_sections, relabel_b=False)
+                                       n_sections, relabel_b=not self.late_relabel)
         ap = self.ops.A_part
         if stages < 1:
             raise ValueError("stages must be at least 1")

@@ -3,7 +3,7 @@
 //
 //   dphpc_amd <algo> <matrix> <run_path> <n_runs> <n_warmup> <shuffle> <partition>
 //             <parallel_load> <persist> <matrix_path>
-//             [--ranks P] [--gpus G] [--impl baseline|drop|shuffle] [--sections N] [--seed S] [--shuffle-iterations I]
+//             [--ranks P] [--gpus G] [--impl baseline|drop|shuffle] [--sections N] [--seed S] [--shuffle-iterations I] [--relabel result|b]
 //
 // <algo>: baseline | outer (no section dropping) | drop | drop_parallel | drop_at_once |
 //         drop_at_once_parallel (bitmap-filtered exchange).  All run the same GPU operator; the
@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     int n_ranks = 0, n_gpus = 0;
     uint32_t n_sections = 512;
     uint64_t seed = 1;
+    std::string relabel_where;         // "", "result" or "b": where a column shuffle is applied
     uint32_t shuffle_iterations = 20; // of the iterative shuffle (the reference stops on wall clock)
     std::string impl;
     for (int i = 1; i < argc; ++i) {
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
       else if (a == "--sections") n_sections = (uint32_t)std::stoul(next());
       else if (a == "--seed") seed = std::stoull(next());
       else if (a == "--shuffle-iterations") shuffle_iterations = (uint32_t)std::stoul(next());
+      else if (a == "--relabel") relabel_where = next();
       else pos.push_back(a);
     }
     if (pos.size() < 10) {
@@ -143,7 +145,10 @@ int main(int argc, char **argv) {
     if (persist_results) partition::save_partitions(partitions, run_path + "/partitions.csv");
 
     // operators, one per rank (reference src/main.cpp:223-310)
-    mults::HipOptions opt{drop, n_sections};
+    mults::HipOptions opt{drop, n_sections, mults::product_rows_are_narrow(tA, *tB)};
+    if (relabel_where == "result") opt.relabel_result = true;
+    else if (relabel_where == "b") opt.relabel_result = false;
+    else if (!relabel_where.empty()) { std::cerr << "--relabel takes result or b\n"; return 1; }
     std::vector<std::unique_ptr<mults::HipSpgemm>> mult(n_nodes);
     for (int rank = 0; rank < n_nodes; ++rank) {
       std::vector<midx_t> keep_rows(A_shuffle.begin() + partitions[rank].start_row, A_shuffle.begin() + partitions[rank].end_row);

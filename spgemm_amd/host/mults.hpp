@@ -84,7 +84,35 @@ public:
 struct HipOptions {
   bool drop = true;          // exchange only the B sections the bitmap marks
   uint32_t n_sections = 512; // the reference's N_SECTIONS (compile-time there, CMakeLists.txt:6)
+  // where a column shuffle is applied: to the result of every multiply (B keeps its column
+  // locality) or to B before the exchange; see product_rows_are_narrow
+  bool relabel_result = true;
 };
+
+// True when most rows of A * B span at most max_span columns (column hull of the B rows a row of A
+// selects): B then has column locality that relabelling it would destroy, and a column shuffle is
+// better applied to the result.  For a B without it (random graphs) sorting the result costs more
+// than it saves.  Reads the whole operands, so every rank comes to the same answer.
+inline bool product_rows_are_narrow(const matrix::Triplets<double> &tA, const matrix::Triplets<double> &tB,
+                                    uint64_t max_span = 65536) {
+  const int64_t none = -1;
+  std::vector<int64_t> bmin(tB.nrows, INT64_MAX), bmax(tB.nrows, none);
+  for (size_t i = 0; i < tB.rows.size(); ++i) {
+    bmin[tB.rows[i]] = std::min<int64_t>(bmin[tB.rows[i]], tB.cols[i]);
+    bmax[tB.rows[i]] = std::max<int64_t>(bmax[tB.rows[i]], tB.cols[i]);
+  }
+  std::vector<int64_t> lo(tA.nrows, INT64_MAX), hi(tA.nrows, none);
+  for (size_t i = 0; i < tA.rows.size(); ++i) {
+    const midx_t k = tA.cols[i];
+    if (bmax[k] == none) continue;
+    lo[tA.rows[i]] = std::min(lo[tA.rows[i]], bmin[k]);
+    hi[tA.rows[i]] = std::max(hi[tA.rows[i]], bmax[k]);
+  }
+  uint64_t live = 0, narrow = 0;
+  for (midx_t r = 0; r < tA.nrows; ++r)
+    if (hi[r] != none) { ++live; narrow += (uint64_t)(hi[r] - lo[r] + 1) <= max_span; }
+  return live > 0 && 2 * narrow >= live;
+}
 
 // Row-wise Gustavson on the GPU for one rank.
 //
@@ -149,9 +177,10 @@ public:
     // to B: a permutation of the columns commutes with the product bit for bit, and B keeps the
     // column locality the kernels live on.  new id of original column c = position of c in col_order
     // (the keep_cols semantics of the loader).
-    matrix::ManagedCSRMatrix<> hB(tB, false, &rows_keep, nullptr);
+    matrix::ManagedCSRMatrix<> hB(tB, false, &rows_keep, opt.relabel_result ? nullptr : col_order);
+    if (!opt.relabel_result) sort_rows(hB); // the loader relabels in place: back to ascending columns
     upload(ctx, hB, &block_B);
-    if (col_order) {
+    if (col_order && opt.relabel_result) {
       bool identity = col_order->size() == b_cols;
       for (size_t p = 0; identity && p < col_order->size(); ++p) identity = (*col_order)[p] == p;
       if (!identity) {
@@ -173,6 +202,26 @@ public:
     measure_point(rank, measure::bitmaps, measure::MeasurementEvent::START);
     bitmap = opt.drop ? bitmap::compute_bitmap(ctx, part_A, opt.n_sections) : std::vector<bool>(opt.n_sections, true);
     measure_point(rank, measure::bitmaps, measure::MeasurementEvent::END);
+  }
+
+  // After relabelling, rows are put back in ascending column order.
+  static void sort_rows(matrix::ManagedCSRMatrix<> &m) {
+    std::vector<std::pair<midx_t, double>> tmp;
+    for (midx_t r = 0; r < m.height; ++r) {
+      midx_t a = m.row_ptr[r], b = m.row_ptr[r + 1];
+      if (std::is_sorted(m.col_idx + a, m.col_idx + b)) continue;
+      tmp.clear();
+      for (midx_t j = a; j < b; ++j) {
+        double v;
+        std::memcpy(&v, reinterpret_cast<std::byte *>(m.values) + (size_t)j * 8, 8);
+        tmp.push_back({m.col_idx[j], v});
+      }
+      std::stable_sort(tmp.begin(), tmp.end(), [](auto &x, auto &y) { return x.first < y.first; });
+      for (midx_t j = a; j < b; ++j) {
+        m.col_idx[j] = tmp[j - a].first;
+        std::memcpy(reinterpret_cast<std::byte *>(m.values) + (size_t)j * 8, &tmp[j - a].second, 8);
+      }
+    }
   }
 
   ~HipSpgemm() override {

@@ -31,10 +31,15 @@ def pg():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("impl", ["baseline", "drop", "shuffle"])
+@pytest.mark.parametrize("impl", ["baseline", "drop", "shuffle", "shuffle:b", "shuffle:result"])
 def test_dist_operator_world1(pg, impl):
+    # shuffle:b / shuffle:result force where the column shuffle is applied (to B before the exchange,
+    # or to the result of the multiply); left alone the operator decides from the operands
+    impl, _, relabel = impl.partition(":")
     A = hostcsr.banded_random(6000, 8, 50, seed=21)
-    op = sd.DistSpgemm(A, None, impl=impl, n_sections=512, seed=5, device_index=0)
+    op = sd.DistSpgemm(A, None, impl=impl, n_sections=512, seed=5, device_index=0, relabel=relabel or None)
+    if relabel:
+        assert op.late_relabel == (relabel == "result")
     op.gemm()
     op.gemm()  # a second run replaces the first result (reset + gemm)
     C = op.result()

@@ -101,3 +101,12 @@ def test_driver_rejects_bad_arguments(tmp_path):
     p = subprocess.run([DRIVER, "comb", "ref_first", str(tmp_path / "x"), "1", "0", "none", "naive", "false", "true",
                         os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
     assert p.returncode == 1 and "Unknown algorithm type" in p.stderr
+
+
+@pytest.mark.parametrize("where", ["result", "b"])
+def test_column_shuffle_applied_to_result_or_to_b(tmp_path, golden_dir, where):
+    """Both places to apply the column shuffle give the reference's C, entry for entry."""
+    run, _ = run_driver(tmp_path, "drop_parallel", "ref_first", shuffle="random",
+                        extra=("--ranks", "3", "--sections", "4", "--relabel", where))
+    M, _, _ = merged(run, 3, 165, 165)
+    orc.assert_same(to_o(M), orc.read_mtx(f"{golden_dir}/ref_first/C_expected.mtx"), rtol=0.0)
