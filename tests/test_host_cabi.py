@@ -94,3 +94,21 @@ def test_mtx_roundtrip(tmp_path, golden_dir):
     s = A.sorted_rows()
     assert np.array_equal(B.row_ptr, s.row_ptr) and np.array_equal(B.col_idx, s.col_idx)
     assert np.array_equal(B.val, s.val)  # 17 significant digits round-trip exactly
+
+
+def test_row_products_and_locality_rule():
+    """Host helpers of the distributed operator: products per row, and the rule that decides where
+    a column shuffle is applied."""
+    from oracle import oracle as orc
+    from spgemm_amd import dist as sd
+    A = hostcsr.rmat(9, 6, seed=4)
+    O = orc.OCsr(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    _, st = orc.spgemm(O, O, with_stats=True)
+    w = sd.row_products(A, A)
+    assert int(w.sum()) == st["nprod"] and len(w) == A.rows
+    band = hostcsr.banded_random(200_000, 4, 50, seed=1)
+    assert sd.product_rows_are_narrow(band, band)                    # a band keeps its columns together
+    er = hostcsr.erdos_renyi(200_000, 4, seed=1)
+    assert not sd.product_rows_are_narrow(er, er)                    # random columns: nothing to lose
+    empty = hostcsr.HostCsr.from_coo(5, 5, [], [], [])
+    assert not sd.product_rows_are_narrow(empty, empty)
