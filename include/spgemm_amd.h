@@ -93,7 +93,6 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   g_thresh0, g_thresh1, g_thresh2                 mean B-row length classes; <= g_thresh2: flat walk
  *   flat_walk, row_groups, big_rows                 0/1 switches of the flat walk, of the grouping of
  *                                                   identical A rows, of the big-row kernels (B sorted)
- *   lds_budget                                      LDS bytes per workgroup aimed for
  *   big_win_words                                   bitmap window of the big-row symbolic kernel
  *                                                   (32-column words, multiple of 1024, <= 32768)
  *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)

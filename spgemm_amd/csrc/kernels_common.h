@@ -29,6 +29,9 @@ constexpr uint32_t GRP_ALEN = 64; // longest A row of such a group (the rows' va
 // "wide" groups: A rows of 65..GRP_ALEN_WIDE entries are grouped by GRP_MAX_WIDE at most (the same
 // LDS holds fewer, longer value lists)
 constexpr uint32_t GRP_MAX_WIDE = 4, GRP_ALEN_WIDE = 128;
+// the smaller of the two wide tiers: A rows of up to GRP_ALEN_MID entries and up to GRP_CAP_MID outputs
+// (3 x 27 = 81 entries and 3 x 125 = 375 outputs: three unknowns per node of a 3-D grid)
+constexpr uint32_t GRP_ALEN_MID = 96, GRP_CAP_MID = 384;
 __host__ __device__ inline uint32_t group_max_rows(uint64_t len_a) { return len_a > GRP_ALEN ? GRP_MAX_WIDE : GRP_MAX; }
 
 struct ClassParams {
@@ -65,18 +68,22 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
 }
 
 // group bins: key = NUM_GRP0 + span_tier * 4 + q; q = 0: up to 128 outputs, q = 1: up to 512 (both:
-// up to GRP_MAX rows of up to GRP_ALEN entries), q = 2: up to 512 outputs, wide group
+// up to GRP_MAX rows of up to GRP_ALEN entries), q = 2: wide group of up to GRP_CAP_MID outputs and
+// GRP_ALEN_MID entries per A row, q = 3: wide group of up to 512 outputs, GRP_ALEN_WIDE entries
 // hash_num_max: most outputs of a row that is accumulated by the LDS hash kernel (<= 4096); rows
 // beyond it go to the big-row bin
 __host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, uint32_t hash_num_max,
-                                               uint32_t group_rows = 1, bool wide = false) {
+                                               uint32_t group_rows = 1, uint32_t len_a = 0) {
   if (nnz == 0) return KEY_NONE;
   uint32_t g = sym_key & 3u;
   if (sym_key < (uint32_t)SYM_HASH0) {
     uint32_t st = sym_key >> 2;
     if (nnz <= 8192u) {
       uint32_t ct = nnz <= 128 ? 0u : nnz <= 512 ? 1u : nnz <= 2048 ? 2u : 3u;
-      if (group_rows > 1 && ct <= 1) return NUM_GRP0 + st * 4 + (wide ? 2u : ct);
+      if (group_rows > 1 && ct <= 1) {
+        if (len_a <= GRP_ALEN) return NUM_GRP0 + st * 4 + ct;
+        return NUM_GRP0 + st * 4 + ((len_a <= GRP_ALEN_MID && nnz <= GRP_CAP_MID) ? 2u : 3u);
+      }
       return NUM_WIN0 + (st * 4 + ct) * 4 + g;
     }
     return NUM_GLOBAL;

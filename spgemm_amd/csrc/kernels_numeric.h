@@ -93,12 +93,14 @@ __global__ void __launch_bounds__(256)
 // once; it is then multiplied by each row's own A value (staged in LDS) and added to that row's
 // accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
 // LDS per wavefront: bmp[words] {bits, prefix} | vals[gmax][cap] | avals[gmax][alen], with
-// (gmax, alen) = (GRP_MAX, GRP_ALEN) or, for wide groups, (GRP_MAX_WIDE, GRP_ALEN_WIDE).
-template <bool WIDE>
+// (gmax, alen) = (GRP_MAX, GRP_ALEN) for TIER 0, (GRP_MAX_WIDE, GRP_ALEN_MID) for TIER 1 and
+// (GRP_MAX_WIDE, GRP_ALEN_WIDE) for TIER 2.
+template <int TIER>
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
                      uint32_t words, uint32_t cap, uint32_t wpb) {
-  constexpr uint32_t gmax = WIDE ? GRP_MAX_WIDE : GRP_MAX, alen = WIDE ? GRP_ALEN_WIDE : GRP_ALEN;
+  constexpr uint32_t gmax = TIER ? GRP_MAX_WIDE : GRP_MAX;
+  constexpr uint32_t alen = TIER == 0 ? GRP_ALEN : TIER == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

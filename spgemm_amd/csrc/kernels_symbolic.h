@@ -65,8 +65,8 @@ __global__ void __launch_bounds__(256)
   const uint32_t cnt = m.gcnt[row];
   if (lane < cnt) {
     m.nnz[row + lane] = n;
-    const bool wide = A.ptr[row + 1] - A.ptr[row] > GRP_ALEN;
-    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, wide);
+    const uint32_t len_a = (uint32_t)min(A.ptr[row + 1] - A.ptr[row], (uint64_t)0xFFFFFFFFu);
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, len_a);
     const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
     m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
   }

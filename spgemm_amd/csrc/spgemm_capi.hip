@@ -73,7 +73,6 @@ struct spgemm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   ClassParams cp;
-  size_t lds_budget = 64 * 1024; // LDS bytes per workgroup aimed for (>= 2 workgroups per CU)
   uint32_t long_len = 2048;      // A rows longer than this are analysed by a whole workgroup
   uint32_t row_groups = 1;       // accumulate runs of identical A rows together
   uint32_t flat_walk = 1;        // rows with short B rows: lay products end to end over the lanes
@@ -253,6 +252,18 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   return SPGEMM_OK;
 }
 
+// Wavefronts per workgroup (1..4) for a kernel that needs `region` bytes of LDS per wavefront: the
+// count that leaves the least of a CU's 160 KiB unused (at most 32 wavefronts fit anyway); the
+// larger workgroup on a tie.
+static uint32_t pick_wpb(size_t region) {
+  uint32_t best_waves = 0, wpb = 1;
+  for (uint32_t w = 1; w <= 4; ++w) {
+    const uint32_t waves = std::min<uint32_t>(32, (uint32_t)((160 * 1024) / (w * region)) * w);
+    if (waves >= best_waves) { best_waves = waves; wpb = w; }
+  }
+  return wpb;
+}
+
 // ---- LDS limits ------------------------------------------------------------------------------------
 template <class K> static void raise_lds_limit(K kernel) {
   hipFuncAttributes fa;
@@ -264,7 +275,7 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
-  raise_lds_limit(k_num_window_grp<true>); raise_lds_limit(k_num_window_grp<false>);
+  raise_lds_limit(k_num_window_grp<0>); raise_lds_limit(k_num_window_grp<1>); raise_lds_limit(k_num_window_grp<2>);
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
@@ -435,9 +446,6 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     ctx->cp.g_thresh1 = (uint32_t)value;
   } else if (n == "g_thresh2") {
     ctx->cp.g_thresh2 = (uint32_t)value;
-  } else if (n == "lds_budget") {
-    if (value < 8192 || value > 160 * 1024) return fail(SPGEMM_ERR_INVALID, "lds_budget must be 8192..163840");
-    ctx->lds_budget = (size_t)value;
   } else if (n == "flat_walk") {
     ctx->flat_walk = value != 0;
   } else if (n == "row_groups") {
@@ -763,7 +771,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t words = (64u << tier) + 2u;
       const bool flat = (key & 3) < 3 && ctx->flat_walk; // short B rows: products laid end to end over the lanes
       size_t region = (size_t)words * 8 + (flat ? FLAT_BYTES : 0);
-      uint32_t wpb = 4;
+      uint32_t wpb = pick_wpb(region);
       st.rows_window += cnt;
       TRY(prof_begin(ctx, 0, 0, flat ? 0 : 64, cnt, words, 0, region * wpb, rows_bin));
       hipLaunchKernelGGL(flat ? k_sym_window<true> : k_sym_window<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
@@ -773,7 +781,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t log2s = 7 + tier;
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
-      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      uint32_t wpb = pick_wpb(region);
       st.rows_hash += cnt;
       if (!flat && log2s >= 12) { // 32 KiB of table and more: the four wavefronts of a workgroup share it
         TRY(prof_begin(ctx, 0, 1, 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
@@ -877,14 +885,16 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
     const uint32_t *rows_bin = perm + boff[key];
     if (key >= NUM_GRP0) {
       uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, q = (uint32_t)(key - NUM_GRP0) & 3;
-      const bool wide = q == 2;
-      uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : 512u;
-      const uint32_t gmax = wide ? GRP_MAX_WIDE : GRP_MAX, alen = wide ? GRP_ALEN_WIDE : GRP_ALEN;
+      const int tier = q < 2 ? 0 : q == 2 ? 1 : 2; // 0: up to 8 rows; 1, 2: wide groups (see num_key_of)
+      uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : 512u;
+      const uint32_t gmax = tier ? GRP_MAX_WIDE : GRP_MAX;
+      const uint32_t alen = tier == 0 ? GRP_ALEN : tier == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
       size_t region = (size_t)words * 8 + (size_t)gmax * cap * 8 + (size_t)gmax * alen * 8;
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
-      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      uint32_t wpb = pick_wpb(region);
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
-      hipLaunchKernelGGL(wide ? k_num_window_grp<true> : k_num_window_grp<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
+      hipLaunchKernelGGL(tier == 0 ? k_num_window_grp<0> : tier == 1 ? k_num_window_grp<1> : k_num_window_grp<2>,
+                         dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb);
     } else if (key < NUM_GLOBAL) {
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
@@ -902,7 +912,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
         region = ((size_t)10 << p0) + (flat ? ((size_t)2 << p0) + FLAT_BYTES : 0);
       }
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
-      uint32_t wpb = (uint32_t)std::min<size_t>(4, std::max<size_t>(1, ctx->lds_budget / region));
+      uint32_t wpb = pick_wpb(region);
       dim3 grid(div_up_u64(cnt, wpb)), block(64 * wpb);
       size_t lds = (size_t)wpb * region;
       TRY(prof_begin(ctx, 1, window ? 0 : 1, flat ? 0 : 64, cnt, p0, p1, lds, rows_bin));
