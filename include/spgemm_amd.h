@@ -109,15 +109,33 @@ int spgemm_mat_from_host(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t
                          const uint64_t *row_ptr, const uint32_t *col_idx, const double *val,
                          spgemm_mat **out);
 /* Wrap device arrays without copying; they must outlive the handle. validate != 0 runs a
- * device pass that checks row_ptr monotonicity and col_idx < cols. */
+ * device pass that checks row_ptr monotonicity and col_idx < cols.
+ * The library caches per-row facts of a matrix the first time it is used as B (column range,
+ * length, whether the row is sorted).  A caller that rewrites the wrapped arrays in place (the
+ * reference refills its receive buffers every gemm, src/mults/drop_parallel.cpp:99-108) must call
+ * spgemm_mat_invalidate before the next multiply; the dimensions and nnz of the handle stay fixed. */
 int spgemm_mat_wrap_device(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uint64_t nnz,
                            const uint64_t *d_row_ptr, const uint32_t *d_col_idx,
                            const double *d_val, int validate, spgemm_mat **out);
+int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m);
 int spgemm_mat_info(const spgemm_mat *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz);
 int spgemm_mat_device_ptrs(const spgemm_mat *m, const uint64_t **d_row_ptr,
                            const uint32_t **d_col_idx, const double **d_val);
 int spgemm_mat_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *row_ptr,
                        uint32_t *col_idx, double *val);
+/* Rows [row0, row0 + nrows) only: row_ptr gets nrows + 1 entries as stored (absolute offsets),
+ * col_idx / val the rows' entries back to back (capacity `cap` entries; NULL skips the array).
+ * What CSRMatrix::row(i) gives the reference's callers (include/matrix_impl.hpp:330-335), for
+ * results too large to bring to the host whole. */
+int spgemm_mat_rows_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t row0, uint64_t nrows,
+                            uint64_t *row_ptr, uint32_t *col_idx, double *val, uint64_t cap);
+/* Invariants of a matrix, checked on the device: fails with SPGEMM_ERR_INVALID when the row pointer
+ * is not a monotone 0..nnz sequence or a column index is >= cols; counts the rows whose columns
+ * are not strictly increasing and the stored values that are exactly 0.0 (both 0 for every
+ * result of spgemm_multiply).  The reference never checks its result's indices
+ * (scripts/compare_matrices.py:18-50 compares the values only). */
+int spgemm_mat_check(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *rows_not_increasing,
+                     uint64_t *zero_values);
 int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m);
 
 /* ---- the multiply: replaces reset() + the local multiply inside gemm()

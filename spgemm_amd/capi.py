@@ -20,8 +20,8 @@ LIB_PATH = os.environ.get("SPGEMM_AMD_LIB") or os.path.join(_HERE, "libspgemm_am
 EXPORTED_SYMBOLS = [
     "spgemm_version", "spgemm_last_error", "spgemm_device_count",
     "spgemm_create", "spgemm_destroy", "spgemm_ctx_device", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option",
-    "spgemm_mat_from_host", "spgemm_mat_wrap_device", "spgemm_mat_info", "spgemm_mat_device_ptrs",
-    "spgemm_mat_to_host", "spgemm_mat_free",
+    "spgemm_mat_from_host", "spgemm_mat_wrap_device", "spgemm_mat_invalidate", "spgemm_mat_info", "spgemm_mat_device_ptrs",
+    "spgemm_mat_to_host", "spgemm_mat_rows_to_host", "spgemm_mat_check", "spgemm_mat_free",
     "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
     "spgemm_section_bitmap",
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
@@ -98,9 +98,12 @@ def load() -> ctypes.CDLL:
         "spgemm_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
         "spgemm_mat_from_host": (i32, [vp, u64, u64, u64, vp, vp, vp, pp]),
         "spgemm_mat_wrap_device": (i32, [vp, u64, u64, u64, vp, vp, vp, i32, pp]),
+        "spgemm_mat_invalidate": (i32, [vp, vp]),
         "spgemm_mat_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         "spgemm_mat_device_ptrs": (i32, [vp, pp, pp, pp]),
         "spgemm_mat_to_host": (i32, [vp, vp, vp, vp, vp]),
+        "spgemm_mat_rows_to_host": (i32, [vp, vp, u64, u64, vp, vp, vp, u64]),
+        "spgemm_mat_check": (i32, [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         "spgemm_mat_free": (i32, [vp, vp]),
         "spgemm_multiply": (i32, [vp, vp, vp, pp]),
         "spgemm_symbolic": (i32, [vp, vp, vp, vp, ctypes.POINTER(u64)]),
@@ -122,6 +125,7 @@ def load() -> ctypes.CDLL:
         "spgemm_buffer_alloc": (i32, [vp, ctypes.c_size_t, pp]),
         "spgemm_buffer_free": (i32, [vp, vp]),
         "spgemm_buffer_copy": (i32, [vp, vp, vp, vp, ctypes.c_size_t]),
+        "spgemm_buffer_upload": (i32, [vp, vp, vp, ctypes.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -195,6 +199,32 @@ class DeviceCsr:
         _check(load().spgemm_mat_to_host(self.ctx.handle, self.handle, _np_ptr(row_ptr), _np_ptr(col_idx),
                                          _np_ptr(val)))
         return row_ptr, col_idx, val
+
+    def rows_to_host(self, row0: int, nrows: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Rows [row0, row0 + nrows): (row_ptr rebased to 0, col_idx, val)."""
+        # two calls: the first reads the row pointer to size the arrays
+        full = np.empty(nrows + 1, dtype=np.uint64)
+        lib = load()
+        rc = lib.spgemm_mat_rows_to_host(self.ctx.handle, self.handle, row0, nrows, _np_ptr(full), None, None,
+                                         ctypes.c_uint64(2 ** 63))
+        _check(rc)
+        n = int(full[-1] - full[0])
+        col = np.empty(n, dtype=np.uint32)
+        val = np.empty(n, dtype=np.float64)
+        _check(lib.spgemm_mat_rows_to_host(self.ctx.handle, self.handle, row0, nrows, _np_ptr(full), _np_ptr(col),
+                                           _np_ptr(val), n))
+        return full - full[0], col, val
+
+    def check(self) -> Tuple[int, int]:
+        """(rows whose columns are not strictly increasing, stored zeros); raises when the row pointer
+        or a column index is out of range."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(load().spgemm_mat_check(self.ctx.handle, self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def invalidate(self):
+        """Drop what the library cached about this matrix (call after rewriting wrapped arrays in place)."""
+        _check(load().spgemm_mat_invalidate(self.ctx.handle, self.handle))
 
     def free(self):
         if self.handle:

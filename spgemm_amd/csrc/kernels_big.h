@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64)
           vals[i * 64u + lane] = 0.0;
         }
       }
-      if (stamp > (1u << 25)) { // claims compare tags: start over before the stamp field overflows
+      if (stamp > CLAIM_STAMP_LIMIT) { // claims compare tags: start over before the stamp field overflows
         for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
         stamp = 0;
       }

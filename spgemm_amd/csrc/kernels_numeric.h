@@ -69,6 +69,12 @@ __global__ void __launch_bounds__(256)
                     [&](uint32_t c, double bv, double av, uint32_t) {
                       const bool live = c != EMPTY_KEY;
                       const uint32_t pos = live ? position(c) : 0u;
+                      if (stamp > CLAIM_STAMP_LIMIT) { // wave-uniform: start the tags over before the stamp field overflows
+                        lds_fence();
+                        for (uint32_t i = lane; i < n; i += 64) owner[i] = 0u;
+                        stamp = 0;
+                        lds_fence();
+                      }
                       claim_in_lane_order(vals, owner, stamp, lane, live && pos < n, pos, __dmul_rn(av, bv));
                     });
   } else {
@@ -231,6 +237,12 @@ __global__ void __launch_bounds__(256)
     flat_walk<true>(A, B, row, lane, reg + 12u * S, [&](uint32_t c, double bv, double av, uint32_t) {
       const uint32_t h = c != EMPTY_KEY ? find(c) : S;
       const bool live = h < S;
+      if (stamp > CLAIM_STAMP_LIMIT) { // wave-uniform: start the tags over before the stamp field overflows
+        lds_fence();
+        for (uint32_t i = lane; i < n; i += 64) owner[i] = 0u;
+        stamp = 0;
+        lds_fence();
+      }
       claim_in_lane_order(vals, owner, stamp, lane, live, live ? (uint32_t)pos[h] : 0u, __dmul_rn(av, bv));
     });
   } else {
@@ -308,7 +320,7 @@ __global__ void __launch_bounds__(256)
     k_count_nonzero(uint32_t rows, const uint64_t *__restrict__ c_ptr, const double *__restrict__ c_val,
                     uint32_t *__restrict__ keep) {
   constexpr int G = 8;
-  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   uint32_t lg = threadIdx.x & (G - 1);
   uint32_t cnt = 0;
   if (row < rows)
@@ -322,7 +334,7 @@ __global__ void __launch_bounds__(256)
     k_compact_rows(uint32_t rows, const uint64_t *__restrict__ old_ptr, const uint32_t *__restrict__ old_col,
                    const double *__restrict__ old_val, const uint64_t *__restrict__ new_ptr,
                    uint32_t *__restrict__ new_col, double *__restrict__ new_val) {
-  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   uint32_t lane = threadIdx.x & 63;
   if (row >= rows) return;
   uint64_t j0 = old_ptr[row], j1 = old_ptr[row + 1];

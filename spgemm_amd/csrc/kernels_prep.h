@@ -71,7 +71,8 @@ template <int G>
 __global__ void __launch_bounds__(256)
     k_analyze(uint32_t rows_a, const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
               const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp, uint32_t long_len) {
-  uint32_t row = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint64_t row64 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint32_t row = row64 < rows_a ? (uint32_t)row64 : rows_a; // rows_a: no row (ids beyond 2^32 / G must not alias)
   uint32_t lg = threadIdx.x & (G - 1);
   uint64_t np = 0;
   uint32_t mn = 0xFFFFFFFFu, mx = 0;

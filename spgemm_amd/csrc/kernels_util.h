@@ -61,6 +61,31 @@ __global__ void __launch_bounds__(256)
     if ((uint64_t)col[j] >= cols) atomicOr(bad, 4u);
 }
 
+// Output invariants: out[0] += rows whose columns are not strictly increasing, out[1] += stored
+// values that are exactly 0.0.  16 lanes per row.
+__global__ void __launch_bounds__(256)
+    k_check_rows(uint64_t rows, const uint64_t *__restrict__ ptr, const uint32_t *__restrict__ col,
+                 const double *__restrict__ val, unsigned long long *__restrict__ out) {
+  constexpr int G = 16;
+  const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint32_t lg = threadIdx.x & (G - 1);
+  uint32_t bad = 0;
+  uint64_t zeros = 0;
+  if (row < rows) {
+    const uint64_t j0 = ptr[row], j1 = ptr[row + 1];
+    for (uint64_t j = j0 + lg; j < j1; j += G) {
+      if (j > j0 && col[j - 1] >= col[j]) bad = 1;
+      zeros += (val[j] == 0.0) ? 1u : 0u;
+    }
+  }
+  bad = group_max<G>(bad);
+  zeros = group_sum64<G>(zeros);
+  if (row < rows && lg == 0) {
+    if (bad) atomicAdd(&out[0], 1ull);
+    if (zeros) atomicAdd(&out[1], (unsigned long long)zeros);
+  }
+}
+
 // ---- operand selection (keep_rows / column relabel) ------------------------------------------------
 __global__ void __launch_bounds__(256)
     k_select_count(uint64_t n_out, const uint32_t *__restrict__ keep_rows, const uint64_t *__restrict__ ptr,

@@ -244,6 +244,9 @@ __device__ __forceinline__ void flat_walk(const Csr &A, const Csr &B, uint32_t r
 // one p add in lane order.  owner[] (one uint32 per accumulator, zero at kernel start) takes
 // claims (stamp << 6 | 63 - lane) by atomic max: the lowest pending lane of the newest round wins
 // its accumulator, adds, and the others try again in the next round.  stamp is wave-uniform.
+// Callers zero owner[] and the stamp again once the stamp passes CLAIM_STAMP_LIMIT: a tag is
+// stamp << 6 | lane, and a wrapped stamp could never win an atomic max again.
+constexpr uint32_t CLAIM_STAMP_LIMIT = 1u << 25;
 __device__ __forceinline__ void claim_in_lane_order(double *vals, uint32_t *owner, uint32_t &stamp, uint32_t lane,
                                                     bool pending, uint32_t p, double prod) {
   for (;;) {

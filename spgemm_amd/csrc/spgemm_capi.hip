@@ -317,28 +317,17 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
   ctx->cp.g_thresh1 = 12;
   ctx->cp.g_thresh2 = 24;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
+  // a failure below releases whatever was created so far (spgemm_destroy copes with a partial context)
+  const char *what = "hipStreamCreate";
   hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    delete ctx;
-    return fail(SPGEMM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-  }
   ctx->stream = ctx->own_stream;
-  for (auto &ev : ctx->ev) {
-    e = hipEventCreate(&ev);
-    if (e != hipSuccess) {
-      delete ctx;
-      return fail(SPGEMM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
-    }
-  }
-  e = hipHostMalloc(&ctx->h_pinned, PINNED_BYTES);
+  for (auto &ev : ctx->ev)
+    if (e == hipSuccess) { what = "hipEventCreate"; e = hipEventCreate(&ev); }
+  if (e == hipSuccess) { what = "hipHostMalloc"; e = hipHostMalloc(&ctx->h_pinned, PINNED_BYTES); }
+  if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc((void **)&ctx->d_small, 4096); }
   if (e != hipSuccess) {
-    delete ctx;
-    return fail(SPGEMM_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
-  }
-  e = hipMalloc((void **)&ctx->d_small, 4096);
-  if (e != hipSuccess) {
-    delete ctx;
-    return fail(SPGEMM_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    (void)spgemm_destroy(ctx);
+    return fail(e == hipErrorOutOfMemory ? SPGEMM_ERR_NOMEM : SPGEMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
   }
   raise_all_lds_limits();
   {
@@ -353,7 +342,7 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
 extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   if (!ctx) return SPGEMM_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   for (auto &b : ctx->buffers) (void)hipFree(b.p);
   if (ctx->arena.p) (void)hipFree(ctx->arena.p);
@@ -578,6 +567,63 @@ extern "C" int spgemm_mat_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t
   if (col_idx && m->nnz) HIP_TRY(hipMemcpyAsync(col_idx, m->d_col, m->nnz * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (val && m->nnz) HIP_TRY(hipMemcpyAsync(val, m->d_val, m->nnz * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+// Invariants of a result matrix, checked on the device (a result of 10^10 entries is not brought to
+// the host to look at it): row pointer monotone and ending at nnz, columns in range, every row
+// strictly increasing (sorted, no duplicates), no stored zero.
+extern "C" int spgemm_mat_check(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *rows_not_increasing,
+                                uint64_t *zero_values) {
+  if (!ctx || !m || !rows_not_increasing || !zero_values) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  TRY(validate_device(ctx, m));
+  unsigned long long *d = reinterpret_cast<unsigned long long *>(ctx->d_small) + 16;
+  HIP_TRY(hipMemsetAsync(d, 0, 16, ctx->stream));
+  if (m->rows) {
+    for (uint64_t r0 = 0; r0 < m->rows; r0 += (1ull << 26)) { // 2^26 rows per launch keep the grid below 2^32 threads
+      const uint64_t nr = std::min<uint64_t>(m->rows - r0, 1ull << 26);
+      hipLaunchKernelGGL(k_check_rows, dim3(div_up_u64(nr * 16, 256)), dim3(256), 0, ctx->stream, nr, m->d_ptr + r0,
+                         m->d_col, m->d_val, d);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  unsigned long long *h = reinterpret_cast<unsigned long long *>(ctx->h_pinned);
+  HIP_TRY(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *rows_not_increasing = h[0];
+  *zero_values = h[1];
+  return SPGEMM_OK;
+}
+
+// Rows [row0, row0 + nrows) of a device matrix to host arrays: row_ptr (nrows + 1 entries, as
+// stored: absolute offsets), col_idx / val (capacity `cap` entries, the rows' entries back to back).
+extern "C" int spgemm_mat_rows_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t row0, uint64_t nrows,
+                                       uint64_t *row_ptr, uint32_t *col_idx, double *val, uint64_t cap) {
+  if (!ctx || !m || !row_ptr) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  if (row0 + nrows > m->rows) return fail(SPGEMM_ERR_INVALID, "row range beyond the matrix");
+  TRY(set_device(ctx));
+  HIP_TRY(hipMemcpyAsync(row_ptr, m->d_ptr + row0, (nrows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint64_t j0 = row_ptr[0], n = row_ptr[nrows] - j0;
+  if (row_ptr[nrows] < j0 || row_ptr[nrows] > m->nnz) return fail(SPGEMM_ERR_STATE, "row pointer is not monotone");
+  if (n > cap) return fail(SPGEMM_ERR_INVALID, "the rows hold %llu entries, capacity is %llu", (unsigned long long)n, (unsigned long long)cap);
+  if (n && col_idx) HIP_TRY(hipMemcpyAsync(col_idx, m->d_col + j0, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (n && val) HIP_TRY(hipMemcpyAsync(val, m->d_val + j0, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
+extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
+  if (!ctx || !m) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  TRY(set_device(ctx));
+  if (ctx->plan.valid && (ctx->plan.A == m || ctx->plan.B == m)) ctx->plan.valid = false;
+  if (m->d_rowinfo) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a queued multiply may still read the row info
+    pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
+    m->d_rowinfo = nullptr;
+    m->bytes_rowinfo = 0;
+  }
   return SPGEMM_OK;
 }
 
@@ -983,15 +1029,31 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
                        d_row_ptr, d_val, keep);
     void *ncol = nullptr, *nval = nullptr, *nptr = nullptr;
     size_t bcol = 0, bval = 0, bptr = 0;
-    TRY(pool_alloc(ctx, keep_nnz * 4, &ncol, &bcol));
-    TRY(pool_alloc(ctx, keep_nnz * 8, &nval, &bval));
-    TRY(pool_alloc(ctx, ((size_t)rows + 1) * 8, &nptr, &bptr));
-    TRY(launch_scan(ctx, keep, rows, (uint64_t *)nptr, partial));
-    hipLaunchKernelGGL(k_compact_rows, dim3(div_up_u64((uint64_t)rows * 64, 256)), dim3(256), 0, ctx->stream, rows,
-                       d_row_ptr, d_col, d_val, (const uint64_t *)nptr, (uint32_t *)ncol, (double *)nval);
-    HIP_TRY(hipGetLastError());
+    int rc = pool_alloc(ctx, keep_nnz * 4, &ncol, &bcol);
+    if (rc == SPGEMM_OK) rc = pool_alloc(ctx, keep_nnz * 8, &nval, &bval);
+    if (rc == SPGEMM_OK) rc = pool_alloc(ctx, ((size_t)rows + 1) * 8, &nptr, &bptr);
+    if (rc == SPGEMM_OK) rc = launch_scan(ctx, keep, rows, (uint64_t *)nptr, partial);
+    if (rc == SPGEMM_OK) {
+      hipLaunchKernelGGL(k_compact_rows, dim3(div_up_u64((uint64_t)rows * 64, 256)), dim3(256), 0, ctx->stream, rows,
+                         d_row_ptr, d_col, d_val, (const uint64_t *)nptr, (uint32_t *)ncol, (double *)nval);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "k_compact_rows launch failed: %s", hipGetErrorString(e));
+    }
+    if (rc != SPGEMM_OK) { // nothing that was taken for the compaction stays behind
+      (void)hipStreamSynchronize(ctx->stream);
+      pool_release(ctx, nptr, bptr);
+      pool_release(ctx, ncol, bcol);
+      pool_release(ctx, nval, bval);
+      return rc;
+    }
     if (allow_realloc && Cmat) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      hipError_t e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+        pool_release(ctx, nptr, bptr);
+        pool_release(ctx, ncol, bcol);
+        pool_release(ctx, nval, bval);
+        return fail(SPGEMM_ERR_HIP, "compaction failed: %s", hipGetErrorString(e));
+      }
       pool_release(ctx, Cmat->d_ptr, Cmat->bytes_ptr);
       pool_release(ctx, Cmat->d_col, Cmat->bytes_col);
       pool_release(ctx, Cmat->d_val, Cmat->bytes_val);
@@ -999,15 +1061,15 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       Cmat->d_col = (uint32_t *)ncol; Cmat->bytes_col = bcol;
       Cmat->d_val = (double *)nval; Cmat->bytes_val = bval;
     } else {
-      HIP_TRY(hipMemcpyAsync(d_row_ptr, nptr, ((size_t)rows + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      if (keep_nnz) {
-        HIP_TRY(hipMemcpyAsync(d_col, ncol, keep_nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_val, nval, keep_nnz * 8, hipMemcpyDeviceToDevice, ctx->stream));
-      }
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      hipError_t e = hipMemcpyAsync(d_row_ptr, nptr, ((size_t)rows + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess && keep_nnz) e = hipMemcpyAsync(d_col, ncol, keep_nnz * 4, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e == hipSuccess && keep_nnz) e = hipMemcpyAsync(d_val, nval, keep_nnz * 8, hipMemcpyDeviceToDevice, ctx->stream);
+      hipError_t e2 = hipStreamSynchronize(ctx->stream);
       pool_release(ctx, nptr, bptr);
       pool_release(ctx, ncol, bcol);
       pool_release(ctx, nval, bval);
+      if (e != hipSuccess || e2 != hipSuccess)
+        return fail(SPGEMM_ERR_HIP, "copying the compacted result failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     }
     *nnz_final = keep_nnz;
     pl.valid = false; // r_nnz was overwritten
@@ -1295,7 +1357,13 @@ extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uin
     std::vector<uint64_t> ptr(n_out + 1);
     std::vector<uint32_t> col(nnz);
     std::vector<double> val(nnz);
-    TRY(spgemm_mat_to_host(ctx, R, ptr.data(), col.data(), val.data()));
+    rc = spgemm_mat_to_host(ctx, R, ptr.data(), col.data(), val.data());
+    if (rc != SPGEMM_OK) {
+      std::string keep = g_err;
+      spgemm_mat_free(ctx, R);
+      g_err = keep;
+      return rc;
+    }
     std::vector<uint32_t> idx;
     std::vector<uint32_t> c2;
     std::vector<double> v2;
@@ -1310,9 +1378,13 @@ extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uin
       std::copy(c2.begin(), c2.end(), col.begin() + j0);
       std::copy(v2.begin(), v2.end(), val.begin() + j0);
     }
-    HIP_TRY(hipMemcpyAsync(R->d_col, col.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(R->d_val, val.data(), nnz * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMemcpyAsync(R->d_col, col.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(R->d_val, val.data(), nnz * 8, hipMemcpyHostToDevice, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream); // the host vectors die with this scope
+    if (e != hipSuccess || e2 != hipSuccess) {
+      spgemm_mat_free(ctx, R);
+      return fail(SPGEMM_ERR_HIP, "uploading the sorted rows failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
   }
   *out = R;
   return SPGEMM_OK;
@@ -1400,6 +1472,44 @@ extern "C" int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32
   return SPGEMM_OK;
 }
 
+// Row pointer of a full-height B from the concatenated row lengths of its present sections.
+// d_len: rows + 1 uint32 of scratch; partial: scan_parts(rows) + 2 uint64 of scratch.
+static int assemble_impl(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections, const uint64_t *bitmap_words,
+                         const uint32_t *d_row_len_concat, uint64_t n_row_len, uint64_t *d_row_ptr_out,
+                         uint64_t *nnz_out, uint32_t *d_len, uint64_t *partial) {
+  // the sections' rows must add up to n_row_len: checked before anything is queued
+  uint64_t src = 0;
+  for (uint32_t s = 0; s < n_sections; ++s) {
+    if (!((bitmap_words[s >> 6] >> (s & 63)) & 1ull)) continue;
+    uint64_t r0, r1;
+    section_rows(rows, n_sections, s, &r0, &r1);
+    src += r1 - r0;
+  }
+  if (src > n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer shorter than the selected sections");
+  if (src < n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer longer than the selected sections");
+  HIP_TRY(hipMemsetAsync(d_len, 0, rows * 4, ctx->stream));
+  src = 0;
+  uint32_t s = 0;
+  while (s < n_sections) {
+    if (!((bitmap_words[s >> 6] >> (s & 63)) & 1ull)) { ++s; continue; }
+    uint32_t e = s;
+    while (e + 1 < n_sections && ((bitmap_words[(e + 1) >> 6] >> ((e + 1) & 63)) & 1ull)) ++e;
+    uint64_t r0, r1, tmp;
+    section_rows(rows, n_sections, s, &r0, &tmp);
+    section_rows(rows, n_sections, e, &tmp, &r1);
+    HIP_TRY(hipMemcpyAsync(d_len + r0, d_row_len_concat + src, (r1 - r0) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    src += r1 - r0;
+    s = e + 1;
+  }
+  TRY(launch_scan(ctx, d_len, rows, d_row_ptr_out, partial));
+  if (nnz_out) {
+    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_row_ptr_out + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *nnz_out = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+  }
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections, const uint64_t *bitmap_words,
                                        const uint32_t *d_row_len_concat, uint64_t n_row_len, uint64_t *d_row_ptr_out,
                                        uint64_t *nnz_out) {
@@ -1413,29 +1523,8 @@ extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t 
   ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
   uint32_t *d_len = ar.take<uint32_t>(rows + 1);
   uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(rows) + 2);
-  HIP_TRY(hipMemsetAsync(d_len, 0, rows * 4, ctx->stream));
-  uint64_t src = 0;
-  uint32_t s = 0;
-  while (s < n_sections) {
-    if (!((bitmap_words[s >> 6] >> (s & 63)) & 1ull)) { ++s; continue; }
-    uint32_t e = s;
-    while (e + 1 < n_sections && ((bitmap_words[(e + 1) >> 6] >> ((e + 1) & 63)) & 1ull)) ++e;
-    uint64_t r0, r1, tmp;
-    section_rows(rows, n_sections, s, &r0, &tmp);
-    section_rows(rows, n_sections, e, &tmp, &r1);
-    if (src + (r1 - r0) > n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer shorter than the selected sections");
-    HIP_TRY(hipMemcpyAsync(d_len + r0, d_row_len_concat + src, (r1 - r0) * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    src += r1 - r0;
-    s = e + 1;
-  }
-  if (src != n_row_len) return fail(SPGEMM_ERR_INVALID, "row length buffer longer than the selected sections");
-  TRY(launch_scan(ctx, d_len, rows, d_row_ptr_out, partial));
-  if (nnz_out) {
-    HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_row_ptr_out + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *nnz_out = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
-  }
-  return SPGEMM_OK;
+  return assemble_impl(ctx, rows, n_sections, bitmap_words, d_row_len_concat, n_row_len, d_row_ptr_out, nnz_out, d_len,
+                       partial);
 }
 
 // ---- raw device buffers -------------------------------------------------------------------------------------

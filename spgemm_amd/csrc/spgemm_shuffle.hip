@@ -61,8 +61,9 @@ __global__ void __launch_bounds__(256)
     k_tr_scatter(uint32_t rows, const uint64_t *__restrict__ ptr, const uint32_t *__restrict__ col,
                  unsigned long long *__restrict__ cursor, uint32_t *__restrict__ tr_row) {
   constexpr uint32_t G = 8;
-  const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) / G, lg = threadIdx.x & (G - 1);
-  if (r >= rows) return;
+  const uint64_t r64 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (r64 >= rows) return;
+  const uint32_t r = (uint32_t)r64, lg = threadIdx.x & (G - 1);
   for (uint64_t j = ptr[r] + lg; j < ptr[r + 1]; j += G) tr_row[atomicAdd(&cursor[col[j]], 1ull)] = r;
 }
 
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(256)
     k_seg_key(uint32_t n, const uint64_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
               const uint32_t *__restrict__ pos, double empty, uint64_t *__restrict__ key) {
   constexpr uint32_t G = 8;
-  const uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) / G, lg = threadIdx.x & (G - 1);
+  const uint64_t s = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint32_t lg = threadIdx.x & (G - 1);
   uint64_t sum = 0, j0 = 0, j1 = 0;
   if (s < n) { j0 = ptr[s]; j1 = ptr[s + 1]; }
   for (uint64_t j = j0 + lg; j < j1; j += G) sum += pos[idx[j]];

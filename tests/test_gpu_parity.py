@@ -305,3 +305,65 @@ def test_unsorted_b_rows_take_the_general_path(ctx):
         check(ctx, A, Bu)
     finally:
         ctx.set_option("window_max_span", 65536)
+
+
+def test_explicit_zero_entries_follow_the_value_rule(ctx):
+    """Stored 0.0 entries in A and B.  The library keeps an output entry iff its accumulated value
+    is != 0 (the rule of scipy, which wrote every C_expected.mtx).  The reference's release build
+    differs in one corner: a product that is exactly 0.0 and arrives as the FIRST product of an
+    entry is inserted and stays (include/matrix_impl.hpp:83-88, the assert is compiled out), so the
+    oracle's result holds explicit zeros there.  Apart from those zero-valued entries the two
+    results are the same, bit for bit."""
+    rng = np.random.default_rng(17)
+    n = 400
+    M = hostcsr.banded_random(n, 7, 25, seed=23)
+    va = M.val.copy()
+    va[rng.random(len(va)) < 0.3] = 0.0          # explicit zeros in A
+    A = hostcsr.HostCsr(n, n, M.row_ptr, M.col_idx, va)
+    vb = M.val.copy()
+    vb[rng.random(len(vb)) < 0.3] = 0.0          # explicit zeros in B
+    B = hostcsr.HostCsr(n, n, M.row_ptr, M.col_idx, vb)
+    C, st = gpu_multiply(ctx, A, B)
+    E = orc.spgemm(to_ocsr(A), to_ocsr(B))
+    assert np.all(C.val != 0.0)
+    zero = E.val == 0.0
+    assert zero.any(), "the case must exercise the corner"
+    keep = ~zero
+    rows_of = np.repeat(np.arange(E.rows), np.diff(E.row_ptr.astype(np.int64)))
+    rp = np.zeros(E.rows + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum(np.bincount(rows_of[keep], minlength=E.rows))
+    orc.assert_same(C, orc.OCsr(E.rows, E.cols, rp, E.col_idx[keep], E.val[keep]), rtol=0.0)
+    assert st["nnz_c"] == int(keep.sum())
+
+
+def test_wrapped_b_refilled_in_place_needs_invalidate(ctx):
+    """A caller that wraps its receive buffers once and refills them every run (as the reference
+    reuses its buffers) calls spgemm_mat_invalidate: the cached per-row facts of B (column range,
+    length, sortedness) are rebuilt."""
+    import torch
+    n = 3000
+    M1 = hostcsr.banded_random(n, 9, 40, seed=31)
+    # same row lengths, mirrored columns stored in DESCENDING order: other column ranges, rows unsorted
+    M2 = hostcsr.HostCsr(n, n, M1.row_ptr, (n - 1 - M1.col_idx.astype(np.int64)).astype(np.uint32), M1.val * 0.5)
+    t_ptr = torch.from_numpy(M1.row_ptr.astype(np.int64)).cuda()
+    t_col = torch.from_numpy(M1.col_idx.view(np.int32).copy()).cuda()
+    t_val = torch.from_numpy(M1.val.copy()).cuda()
+    torch.cuda.synchronize()
+    dB = ctx.wrap_device(n, n, M1.nnz, t_ptr.data_ptr(), t_col.data_ptr(), t_val.data_ptr(), validate=True,
+                         keepalive=(t_ptr, t_col, t_val))
+    dA = ctx.from_host(M1.rows, M1.cols, M1.row_ptr, M1.col_idx, M1.val)
+
+    def run():
+        dC = ctx.multiply(dA, dB)
+        rp, ci, v = dC.to_host()
+        dC.free()
+        return orc.OCsr(n, n, rp, ci, v)
+
+    orc.assert_same(run(), orc.spgemm(to_ocsr(M1), to_ocsr(M1)), rtol=0.0)
+    t_col.copy_(torch.from_numpy(M2.col_idx.view(np.int32).copy()))
+    t_val.copy_(torch.from_numpy(M2.val.copy()))
+    torch.cuda.synchronize()
+    dB.invalidate()
+    orc.assert_same(run(), orc.spgemm(to_ocsr(M1), to_ocsr(M2)), rtol=0.0)
+    dB.free()
+    dA.free()
