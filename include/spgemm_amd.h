@@ -252,6 +252,16 @@ int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t n_sectio
 int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
                             const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
                             uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out);
+/* spgemm_assemble_row_ptr for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops that call it once per exchange step, harnesses that forbid hipMalloc): same
+ * arguments, same result, but no hipMalloc / hipFree or allocating library routine is called.  It
+ * has no counterpart in the reference.  Its scratch (row lengths and scan partials, 16 MiB) is a
+ * static device array of the library: at most 4,194,304 rows (SPGEMM_ERR_UNSUPPORTED beyond).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (from different
+ * contexts or streams) race; calls on one context are ordered by its stream. */
+int spgemm_assemble_row_ptr_noalloc(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
+                                    const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
+                                    uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out);
 
 /* ---- raw device buffers for the exchange: what the reference keeps in std::vector<std::byte>
  *      receive buffers (src/mults/drop_parallel.cpp:65-68) lives in HBM here.  copy moves bytes

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "spgemm_section_bitmap",
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
     "spgemm_shuffle_random", "spgemm_shuffle_iterative", "spgemm_mat_select", "spgemm_mat_relabel_columns",
-    "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr",
+    "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr", "spgemm_assemble_row_ptr_noalloc",
     "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy", "spgemm_buffer_upload",
 ]
 
@@ -124,6 +124,7 @@ def load() -> ctypes.CDLL:
         "spgemm_assemble_row_ptr": (i32, [vp, u64, u32, vp, vp, u64, vp, ctypes.POINTER(u64)]),
         "spgemm_buffer_alloc": (i32, [vp, ctypes.c_size_t, pp]),
         "spgemm_buffer_free": (i32, [vp, vp]),
+        "spgemm_assemble_row_ptr_noalloc": (i32, [vp, u64, u32, vp, vp, u64, vp, ctypes.POINTER(u64)]),
         "spgemm_buffer_copy": (i32, [vp, vp, vp, vp, ctypes.c_size_t]),
         "spgemm_buffer_upload": (i32, [vp, vp, vp, ctypes.c_size_t]),
     }
@@ -388,10 +389,12 @@ class Context:
         return r.value, n.value
 
     def assemble_row_ptr(self, rows: int, n_sections: int, bits: np.ndarray, d_row_len_concat: int, n_row_len: int,
-                         d_row_ptr_out: int) -> int:
+                         d_row_ptr_out: int, noalloc: bool = False) -> int:
+        """noalloc=True: the variant that allocates nothing (at most 2^22 rows)."""
         words = bitmap_words(bits)
         n = ctypes.c_uint64()
-        _check(load().spgemm_assemble_row_ptr(self.handle, rows, n_sections, _np_ptr(words),
+        fn = load().spgemm_assemble_row_ptr_noalloc if noalloc else load().spgemm_assemble_row_ptr
+        _check(fn(self.handle, rows, n_sections, _np_ptr(words),
                                               ctypes.c_void_p(d_row_len_concat), n_row_len,
                                               ctypes.c_void_p(d_row_ptr_out), ctypes.byref(n)))
         return n.value

@@ -91,6 +91,7 @@ struct spgemm_ctx {
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
+  unsigned char *noalloc_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress)
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
   std::vector<Block> buffers; // live blocks handed out by spgemm_buffer_alloc
   size_t pool_bytes = 0;
@@ -127,6 +128,17 @@ struct spgemm_ctx {
 
 static constexpr size_t PINNED_BYTES = 8192;
 static constexpr size_t POOL_LIMIT_BLOCKS = 16;
+
+// ---- scratch of the allocation-free entry point -----------------------------------------------------
+// spgemm_assemble_row_ptr_noalloc keeps its row lengths and scan partials here instead of in the
+// context's arena (which grows through hipMalloc).  One copy per GPU, held until the process ends;
+// every call on a GPU shares it.  The array's name is only a host-side stand-in: host code uses the
+// address hipGetSymbolAddress returned for the context's device (spgemm_ctx::noalloc_scratch).
+static constexpr uint64_t NOALLOC_MAX_ROWS = 1ull << 22;
+static constexpr size_t NOALLOC_LEN_BYTES = ((NOALLOC_MAX_ROWS + 1) * 4 + 255) / 256 * 256;
+static constexpr size_t NOALLOC_PARTIAL_BYTES =
+    (((NOALLOC_MAX_ROWS + (uint64_t)SCAN_BLOCK * SCAN_ITEMS - 1) / ((uint64_t)SCAN_BLOCK * SCAN_ITEMS) + 2) * 8 + 255) / 256 * 256;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_LEN_BYTES + NOALLOC_PARTIAL_BYTES];
 
 // ---- helpers ------------------------------------------------------------------------------------
 static int set_device(const spgemm_ctx *ctx) {
@@ -325,6 +337,8 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
     if (e == hipSuccess) { what = "hipEventCreate"; e = hipEventCreate(&ev); }
   if (e == hipSuccess) { what = "hipHostMalloc"; e = hipHostMalloc(&ctx->h_pinned, PINNED_BYTES); }
   if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc((void **)&ctx->d_small, 4096); }
+  // address of this device's copy of the allocation-free entry point's scratch array
+  if (e == hipSuccess) { what = "hipGetSymbolAddress"; e = hipGetSymbolAddress((void **)&ctx->noalloc_scratch, HIP_SYMBOL(scratch)); }
   if (e != hipSuccess) {
     (void)spgemm_destroy(ctx);
     return fail(e == hipErrorOutOfMemory ? SPGEMM_ERR_NOMEM : SPGEMM_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
@@ -1523,6 +1537,24 @@ extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t 
   ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
   uint32_t *d_len = ar.take<uint32_t>(rows + 1);
   uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(rows) + 2);
+  return assemble_impl(ctx, rows, n_sections, bitmap_words, d_row_len_concat, n_row_len, d_row_ptr_out, nnz_out, d_len,
+                       partial);
+}
+
+// The same result as spgemm_assemble_row_ptr without any allocation: the row lengths and the scan
+// partials live in this device's copy of `scratch` (address taken once, in spgemm_create).
+extern "C" int spgemm_assemble_row_ptr_noalloc(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
+                                               const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
+                                               uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out) {
+  if (!ctx || !bitmap_words || !d_row_ptr_out || n_sections == 0) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  if (rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "rows / n_sections == 0");
+  if (rows > NOALLOC_MAX_ROWS)
+    return fail(SPGEMM_ERR_UNSUPPORTED, "spgemm_assemble_row_ptr_noalloc handles at most %llu rows (got %llu); use "
+                "spgemm_assemble_row_ptr", (unsigned long long)NOALLOC_MAX_ROWS, (unsigned long long)rows);
+  if (!ctx->noalloc_scratch) return fail(SPGEMM_ERR_STATE, "internal: the scratch array has no device address");
+  TRY(set_device(ctx));
+  uint32_t *d_len = reinterpret_cast<uint32_t *>(ctx->noalloc_scratch);
+  uint64_t *partial = reinterpret_cast<uint64_t *>(ctx->noalloc_scratch + NOALLOC_LEN_BYTES);
   return assemble_impl(ctx, rows, n_sections, bitmap_words, d_row_len_concat, n_row_len, d_row_ptr_out, nnz_out, d_len,
                        partial);
 }
