@@ -90,6 +90,11 @@ int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
 int spgemm_synchronize(spgemm_ctx *ctx);
 /* Tunables, by name; unknown names are an error.
  *   window_max_span, window_ratio, hash_max_nprod   row binning (window / LDS hash / big rows)
+ *   short_max_nprod                                 rows outside the window path with at most this many
+ *                                                   products (<= 512) and at most 64 A entries take the
+ *                                                   short-row kernels (count-only symbolic pass, numeric
+ *                                                   pass that sorts the row's products itself); 0: none
+ *   short_rpw                                       rows one wavefront of those kernels pipelines
  *   g_thresh0, g_thresh1, g_thresh2                 mean B-row length classes; <= g_thresh2: flat walk
  *   flat_walk, row_groups, big_rows                 0/1 switches of the flat walk, of the grouping of
  *                                                   identical A rows, of the big-row kernels (B sorted)

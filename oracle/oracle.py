@@ -50,6 +50,8 @@ def lib() -> ctypes.CDLL:
         vp = ctypes.c_void_p
         L.oracle_spgemm.restype = vp
         L.oracle_spgemm.argtypes = [ctypes.c_uint64, vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int]
+        L.oracle_spgemm_spa.restype = vp
+        L.oracle_spgemm_spa.argtypes = [ctypes.c_uint64, vp, vp, vp, ctypes.c_uint64, vp, vp, vp, ctypes.c_int]
         L.oracle_spgemm_blocks.restype = vp
         L.oracle_spgemm_blocks.argtypes = [ctypes.c_uint64, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp,
                                            ctypes.c_int, ctypes.c_int]
@@ -178,6 +180,17 @@ def spgemm(A: OCsr, B: OCsr, sort_cols: bool = True, nthreads: int = 0, with_sta
     ap, ac, av = _c(A.row_ptr, np.uint64), _c(A.col_idx, np.uint32), _c(A.val, np.float64)
     bp, bc, bv = _c(B.row_ptr, np.uint64), _c(B.col_idx, np.uint32), _c(B.val, np.float64)
     h = lib().oracle_spgemm(A.rows, _p(ap), _p(ac), _p(av), _p(bp), _p(bc), _p(bv), int(sort_cols), nthreads)
+    C, st = _take(h, B.cols)
+    return (C, st) if with_stats else C
+
+
+def spgemm_spa(A: OCsr, B: OCsr, nthreads: int = 0, with_stats: bool = False):
+    """C = A * B by a tuned CPU Gustavson with a dense accumulator per thread (not the reference's
+    accumulator: the second, fairer line of the CPU baseline).  Keeps an entry iff its value != 0."""
+    assert A.cols == B.rows
+    ap, ac, av = _c(A.row_ptr, np.uint64), _c(A.col_idx, np.uint32), _c(A.val, np.float64)
+    bp, bc, bv = _c(B.row_ptr, np.uint64), _c(B.col_idx, np.uint32), _c(B.val, np.float64)
+    h = lib().oracle_spgemm_spa(A.rows, _p(ap), _p(ac), _p(av), B.cols, _p(bp), _p(bc), _p(bv), nthreads)
     C, st = _take(h, B.cols)
     return (C, st) if with_stats else C
 

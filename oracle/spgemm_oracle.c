@@ -287,6 +287,130 @@ oracle_result_t *oracle_spgemm(uint64_t rows_a, const uint64_t *a_ptr,
 }
 
 /*
+ * A tuned CPU Gustavson with a dense sparse accumulator (SPA) per thread: value and stamp arrays
+ * of one entry per column of B, a list of the touched columns.  Two passes (count, then fill), as
+ * CPU SpGEMM libraries do.  NOT the reference's algorithm: it is the "fair second line" of the CPU
+ * baseline next to the map-per-row port of reference src/mults/drop_parallel.cpp:43-59, and keeps an
+ * entry iff its accumulated value is != 0.  Products are added in the same (A row, B row) order, so
+ * the values are the reference's; rows come out sorted by column.
+ * seconds_accumulate = both passes, without the per-row sort of the output.
+ */
+oracle_result_t *oracle_spgemm_spa(uint64_t rows_a, const uint64_t *a_ptr,
+                                   const midx_t *a_col, const double *a_val,
+                                   uint64_t cols_b, const uint64_t *b_ptr,
+                                   const midx_t *b_col, const double *b_val,
+                                   int nthreads) {
+  oracle_result_t *r = (oracle_result_t *)calloc(1, sizeof(*r));
+  r->rows = rows_a;
+  r->row_ptr = (uint64_t *)calloc(rows_a + 1, sizeof(uint64_t));
+  uint64_t nprod_total = 0;
+#ifdef _OPENMP
+  if (nthreads > 0)
+    omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  double t0 = now_s();
+  /* pass 1: structural count per row */
+#pragma omp parallel reduction(+ : nprod_total)
+  {
+    uint64_t *stamp = (uint64_t *)calloc(cols_b ? cols_b : 1, sizeof(uint64_t));
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t row = 0; row < (int64_t)rows_a; ++row) {
+      uint64_t n = 0;
+      for (uint64_t ka = a_ptr[row]; ka < a_ptr[row + 1]; ++ka) {
+        midx_t k = a_col[ka];
+        for (uint64_t jb = b_ptr[k]; jb < b_ptr[k + 1]; ++jb) {
+          midx_t c = b_col[jb];
+          if (stamp[c] != (uint64_t)row + 1) {
+            stamp[c] = (uint64_t)row + 1;
+            ++n;
+          }
+          nprod_total++;
+        }
+      }
+      r->row_ptr[row + 1] = n;
+    }
+    free(stamp);
+  }
+  for (uint64_t i = 0; i < rows_a; ++i)
+    r->row_ptr[i + 1] += r->row_ptr[i];
+  uint64_t cap = r->row_ptr[rows_a];
+  midx_t *col = (midx_t *)malloc((cap ? cap : 1) * sizeof(midx_t));
+  double *val = (double *)malloc((cap ? cap : 1) * sizeof(double));
+  /* pass 2: accumulate and gather (touch order) */
+#pragma omp parallel
+  {
+    uint64_t *stamp = (uint64_t *)calloc(cols_b ? cols_b : 1, sizeof(uint64_t));
+    double *acc = (double *)malloc((cols_b ? cols_b : 1) * sizeof(double));
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t row = 0; row < (int64_t)rows_a; ++row) {
+      uint64_t base = r->row_ptr[row], n = 0;
+      for (uint64_t ka = a_ptr[row]; ka < a_ptr[row + 1]; ++ka) {
+        midx_t k = a_col[ka];
+        double av = a_val[ka];
+        for (uint64_t jb = b_ptr[k]; jb < b_ptr[k + 1]; ++jb) {
+          midx_t c = b_col[jb];
+          double p = av * b_val[jb];
+          if (stamp[c] != (uint64_t)row + 1) {
+            stamp[c] = (uint64_t)row + 1;
+            acc[c] = p;
+            col[base + n++] = c;
+          } else {
+            acc[c] += p;
+          }
+        }
+      }
+      for (uint64_t i = 0; i < n; ++i)
+        val[base + i] = acc[col[base + i]];
+    }
+    free(stamp);
+    free(acc);
+  }
+  r->seconds_accumulate = now_s() - t0;
+  r->nprod = nprod_total;
+  /* sort every row by column, drop exact zeros, compact (not timed) */
+  uint64_t *keep = (uint64_t *)calloc(rows_a + 1, sizeof(uint64_t));
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t row = 0; row < (int64_t)rows_a; ++row) {
+    uint64_t base = r->row_ptr[row], n = r->row_ptr[row + 1] - base;
+    if (!n)
+      continue;
+    entry_t *e = (entry_t *)malloc(n * sizeof(entry_t));
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i)
+      if (val[base + i] != 0) {
+        e[w].col = col[base + i];
+        e[w].val = val[base + i];
+        e[w].order = 0;
+        ++w;
+      }
+    qsort(e, w, sizeof(entry_t), cmp_col);
+    for (uint64_t i = 0; i < w; ++i) {
+      col[base + i] = e[i].col;
+      val[base + i] = e[i].val;
+    }
+    keep[row + 1] = w;
+    free(e);
+  }
+  for (uint64_t i = 0; i < rows_a; ++i)
+    keep[i + 1] += keep[i];
+  r->nnz = keep[rows_a];
+  r->col_idx = (midx_t *)malloc((r->nnz ? r->nnz : 1) * sizeof(midx_t));
+  r->val = (double *)malloc((r->nnz ? r->nnz : 1) * sizeof(double));
+  for (uint64_t row = 0; row < rows_a; ++row) {
+    uint64_t n = keep[row + 1] - keep[row];
+    memcpy(r->col_idx + keep[row], col + r->row_ptr[row], n * sizeof(midx_t));
+    memcpy(r->val + keep[row], val + r->row_ptr[row], n * sizeof(double));
+  }
+  memcpy(r->row_ptr, keep, (rows_a + 1) * sizeof(uint64_t));
+  free(keep);
+  free(col);
+  free(val);
+  return r;
+}
+
+/*
  * Baseline operator: inner-product SpGEMM over a TRANSPOSED B block (row j of
  * bt_* is column j of B), sorted merge-join of A row and B column, emits only
  * res != 0.  Reference src/mults/baseline.cpp:48-71.  Requires column indices

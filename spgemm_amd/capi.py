@@ -279,6 +279,15 @@ class Context:
     def synchronize(self):
         _check(load().spgemm_synchronize(self.handle))
 
+    def stream_copy_rate(self, nbytes: int = 1 << 30, reps: int = 5) -> float:
+        """GB/s (read + write) of a plain streaming copy on this GPU: the achievable HBM rate."""
+        fn = load().spgemm_internal_stream_copy_rate
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        out = ctypes.c_double(0.0)
+        _check(fn(self.handle, nbytes, reps, ctypes.byref(out)))
+        return out.value
+
     # -- matrices ---------------------------------------------------------------------------------
     def from_host(self, rows: int, cols: int, row_ptr, col_idx, val) -> DeviceCsr:
         row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)

@@ -21,4 +21,5 @@
 #include "kernels_symbolic.h"
 #include "kernels_numeric.h"
 #include "kernels_big.h"
+#include "kernels_short.h"
 #include "kernels_util.h"

@@ -39,7 +39,11 @@ struct ClassParams {
   uint32_t win_ratio;      // ... and only if span <= win_ratio * nprod
   uint32_t hash_max_nprod; // LDS hash symbolic up to this many products (<= 4096)
   uint32_t g_thresh0, g_thresh1, g_thresh2; // mean B-row length thresholds for 8/16/32 lanes
+  uint32_t short_max_nprod; // rows of the hash path with at most this many products take the short-row kernels (0: none)
 };
+// Short rows (kernels_short.h): at most SH_MAX_NPROD products and SH_MAX_ALEN entries in the A row.
+// In the hash bins sub-bin 0 (key & 3 == 0) is theirs alone; the other rows use sub-bins 1..3.
+constexpr uint32_t SH_MAX_NPROD = 512, SH_MAX_ALEN = 64;
 
 __host__ __device__ inline uint32_t ceil_log2_u32(uint32_t x) {
   uint32_t l = 0;
@@ -62,7 +66,8 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
   }
   if (nprod <= p.hash_max_nprod) {
     uint32_t t = ceil_log2_u32(nprod < 64u ? 64u : (uint32_t)nprod) - 6u; // nprod <= 64 << t
-    return SYM_HASH0 + t * 4 + g;
+    if (nprod <= p.short_max_nprod && nprod <= SH_MAX_NPROD && len_a <= SH_MAX_ALEN) return SYM_HASH0 + t * 4;
+    return SYM_HASH0 + t * 4 + (g ? g : 1u);
   }
   return SYM_GLOBAL0 + g;
 }
@@ -76,6 +81,8 @@ __host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, u
                                                uint32_t group_rows = 1, uint32_t len_a = 0) {
   if (nnz == 0) return KEY_NONE;
   uint32_t g = sym_key & 3u;
+  if (sym_key >= (uint32_t)SYM_HASH0 && sym_key < (uint32_t)SYM_GLOBAL0 && g == 0u) // short row: its own numeric
+    return NUM_HASH0 + (sym_key - (uint32_t)SYM_HASH0);                               // kernel, tiers by products
   if (sym_key < (uint32_t)SYM_HASH0) {
     uint32_t st = sym_key >> 2;
     if (nnz <= 8192u) {
@@ -90,7 +97,7 @@ __host__ __device__ inline uint32_t num_key_of(uint32_t sym_key, uint32_t nnz, u
   }
   if (nnz <= hash_num_max) {
     uint32_t ct = ceil_log2_u32(nnz < 64u ? 64u : nnz) - 6u; // nnz <= 64 << ct
-    return NUM_HASH0 + ct * 4 + g;
+    return NUM_HASH0 + ct * 4 + (g ? g : 1u);             // sub-bin 0 belongs to the short rows
   }
   return NUM_GLOBAL;
 }

@@ -5,9 +5,10 @@
 
 namespace sg {
 
-// ---- B row info: {min col, max col, length, 1 if the row's columns are not strictly increasing}
-// of every B row; info[rows].x counts the rows that are not strictly increasing (zero on entry).
-// 8 lanes per row.
+// ---- B row info: two uint4 per row, {min col, max col, length, 1 if the row's columns are not strictly
+// increasing} and {start of the row in B.col / B.val (low, high word), 0, 0}: everything the analysis
+// of an A entry needs about its B row sits in one 32-byte record.  info[2 * rows].x counts the rows
+// that are not strictly increasing (zero on entry).  8 lanes per row.
 __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
                                                    const uint32_t *__restrict__ b_col,
                                                    uint4 *__restrict__ info) {
@@ -31,8 +32,9 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
   unsorted = group_max<G>(unsorted);
   if (row < rows && lg == 0) {
     uint64_t len = b1 - b0;
-    info[row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
-    if (unsorted) atomicAdd(&info[rows].x, 1u);
+    info[2 * row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
+    info[2 * row + 1] = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), 0u, 0u);
+    if (unsorted) atomicAdd(&info[2 * rows].x, 1u);
   }
 }
 
@@ -50,6 +52,8 @@ struct AnalyzeOut {
   uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
   uint32_t *long_count;
   uint8_t *r_same;         // 1 when the row's column list equals the previous row's (same order)
+  uint64_t *a_p0;          // per A entry of a short row (kernels_short.h): start of its B row ...
+  uint32_t *a_len;         // ... and the B row's length (both may be null: no short rows)
 };
 
 __device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32_t mn, uint32_t mx,
@@ -60,6 +64,8 @@ __device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32
   uint64_t ub = np;
   if (key != KEY_NONE && (key < (uint32_t)SYM_HASH0 || key >= (uint32_t)SYM_GLOBAL0))
     ub = np < span ? np : span;
+  else if (key != KEY_NONE && (key & 3u) == 0u)
+    ub = 0; // short row: its symbolic pass only counts, no column list is kept
   o.r_cmin[row] = mn;
   o.r_cmax[row] = mx;
   o.r_ub[row] = (uint32_t)ub;
@@ -96,7 +102,7 @@ __global__ void __launch_bounds__(256)
     for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
       uint32_t kcol = a_col[ka];
       if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
-      uint4 bi = b_info[kcol];
+      uint4 bi = b_info[2 * (size_t)kcol];
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);
@@ -108,6 +114,19 @@ __global__ void __launch_bounds__(256)
   np = group_sum64<G>(np);
   mn = group_min<G>(mn);
   mx = group_max<G>(mx);
+  // a short row leaves, per A entry, the start and length of the B row for its two kernels (the
+  // records were just read: these loads hit the caches)
+  if (row < rows_a && !is_long && o.a_p0) {
+    const uint32_t len_a = (uint32_t)(a1 - a0);
+    const uint32_t key = sym_key_of(np, np ? (mx - mn + 1u) : 0u, len_a, cp);
+    if (key >= (uint32_t)SYM_HASH0 && key < (uint32_t)SYM_GLOBAL0 && (key & 3u) == 0u)
+      for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
+        const size_t k = a_col[ka];
+        const uint4 lo = b_info[2 * k], hi = b_info[2 * k + 1];
+        o.a_p0[ka] = ((uint64_t)hi.y << 32) | hi.x;
+        o.a_len[ka] = lo.z;
+      }
+  }
   uint64_t contrib = 0;
   if (row < rows_a && lg == 0) {
     o.r_same[row] = differs ? 0 : 1;
@@ -144,7 +163,7 @@ __global__ void __launch_bounds__(256)
     uint64_t np = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
     for (uint64_t ka = a0 + threadIdx.x; ka < a1; ka += blockDim.x) {
-      uint4 bi = b_info[a_col[ka]];
+      uint4 bi = b_info[2 * (size_t)a_col[ka]];
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);

@@ -1,0 +1,348 @@
+// Short rows outside the window path (wide column hull, few products): count-only symbolic pass and a
+// numeric pass that builds its own sorted pattern, so no column list travels between the two.
+// Part of the gfx950 SpGEMM kernels; included through kernels.h.
+#pragma once
+#include "kernels_numeric.h"
+
+namespace sg {
+
+// A row takes this path when it has at most SH_MAX_NPROD products and at most SH_MAX_ALEN entries
+// in its A row (the whole A row then sits in one wavefront, one entry per lane).
+constexpr int SH_STEPS = SH_MAX_NPROD / 64; // steps of 64 products a row can take
+// per-wavefront walk scratch: st[64] u32 | p0s[64] u64 | avs[2][64] f64 | marks[SH_MAX_NPROD] u8
+constexpr uint32_t SH_SCRATCH = 256 + 512 + 1024 + SH_MAX_NPROD;
+
+// Monotone map of the columns of B onto [0, nnz(B)]: F(c) = number of entries of B in columns < c,
+// piecewise linear over CDF_BINS equal column ranges (cdf[b] = entries in the bins before b, exact
+// integers held as doubles).  A row's columns, drawn from B's rows, are spread evenly by F whatever
+// the popularity of B's columns (R-MAT hubs), which keeps the clusters of the sorted table short.
+constexpr uint32_t CDF_BINS = 2048;
+struct ColMap {
+  const double *__restrict__ cdf; // CDF_BINS + 1 entries
+  uint32_t shift;                 // bin of column c = c >> shift
+  double inv_width;               // 2^-shift
+};
+__device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
+  const uint32_t b = c >> cm.shift;
+  const double lo = cm.cdf[b], hi = cm.cdf[b + 1];
+  const double frac = (double)(c - (b << cm.shift)) * cm.inv_width;
+  return lo + (hi - lo) * frac;
+}
+
+// inclusive max-scan over the 64 lanes (0 is the identity)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+  v = max(v, dpp_move<0x111>(0u, v));
+  v = max(v, dpp_move<0x112>(0u, v));
+  v = max(v, dpp_move<0x114>(0u, v));
+  v = max(v, dpp_move<0x118>(0u, v));
+  v = max(v, dpp_move<0x142, 0xA>(0u, v));
+  v = max(v, dpp_move<0x143, 0xC>(0u, v));
+  return v;
+}
+
+// A wavefront takes `rpw` consecutive rows of its bin and pipelines them: while row i is worked on in
+// LDS, the B entries of row i + 1 are in flight (their addresses need the A entries and the B row
+// bounds, which were fetched while row i - 1 was worked on) and the A entries of row i + 2 are being
+// fetched.  Without this a wavefront has loads in flight for a third of its life, and the kernels
+// are bound by memory latency at the occupancy their LDS tables allow.
+//
+// Stage A (ShortFetch): lane t holds A entry t of the row: its value, start and length of B row k.
+struct ShortFetch {
+  uint32_t row, len, n, cmin, cmax;
+  uint64_t p0, off;
+  double av;
+};
+template <bool NUMERIC>
+__device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const RowMeta &m, const uint64_t *c_ptr,
+                                            const uint32_t *rows, uint32_t idx, uint32_t lane, ShortFetch &f) {
+  f.row = scalar_view(rows)[idx];
+  const uint64_t a0 = scalar_view(A.ptr)[f.row], a1 = scalar_view(A.ptr)[f.row + 1];
+  if constexpr (NUMERIC) {
+    f.n = scalar_view((const uint32_t *)m.nnz)[f.row];
+    f.off = scalar_view(c_ptr)[f.row];
+    f.cmin = scalar_view(m.cmin)[f.row];
+    f.cmax = scalar_view(m.cmax)[f.row];
+  }
+  const uint64_t ka = a0 + lane;
+  f.len = 0;
+  f.p0 = 0;
+  f.av = 0.0;
+  if (ka < a1) { // start and length of the B row: left per A entry by the analysis, read in a stream
+    f.p0 = m.a_p0[ka];
+    f.len = m.a_len[ka];
+    if constexpr (NUMERIC) f.av = A.val[ka];
+  }
+}
+
+// Stage B (ShortSet): the products of the row, 64 per step, product q of the row (A order, then B
+// row order) in lane q % 64 of step q / 64.  The exclusive prefix sums of the B row lengths go to
+// LDS and a byte array marks, at each entry's first product, the entry (t + 1); a step reads its 64
+// marks, and a running max over the lanes (and over the steps) gives every product its entry: no
+// search.  The loads of the B entries are issued here and consumed by stage C of the same row, one
+// row later in program order.
+// LDS scratch per wavefront: st[64] u32 | p0s[64] u64 | avs[2][64] f64 | marks[SH_MAX_NPROD] u8; the
+// A values are kept for stage C in the half of avs that `parity` names.
+// STEPS: steps of 64 products the rows of the launch can take.
+template <bool NUMERIC, int STEPS> struct ShortSet {
+  uint32_t c[STEPS], t[STEPS];
+  double bv[STEPS];
+  uint32_t row, total, n, cmin, cmax;
+  uint64_t off;
+  double f[4]; // column map around cmin and cmax (numeric)
+};
+template <bool NUMERIC, int STEPS>
+__device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, const ShortFetch &f, uint32_t lane,
+                                             unsigned char *scratch, uint32_t parity, ShortSet<NUMERIC, STEPS> &s) {
+  uint32_t *st = reinterpret_cast<uint32_t *>(scratch);
+  uint64_t *p0s = reinterpret_cast<uint64_t *>(scratch + 256);
+  double *avs = reinterpret_cast<double *>(scratch + 768) + 64u * parity;
+  uint8_t *marks = scratch + 1792;
+  s.row = f.row;
+  if constexpr (NUMERIC) {
+    s.n = f.n; s.off = f.off; s.cmin = f.cmin; s.cmax = f.cmax;
+    const uint32_t b0 = f.cmin >> cm.shift, b1 = f.cmax >> cm.shift;
+    s.f[0] = cm.cdf[b0]; s.f[1] = cm.cdf[b0 + 1]; s.f[2] = cm.cdf[b1]; s.f[3] = cm.cdf[b1 + 1];
+  }
+  lds_fence(); // the scratch of the row before has been read
+  reinterpret_cast<uint64_t *>(marks)[lane] = 0ull; // SH_MAX_NPROD = 64 * 8 bytes
+  const uint32_t incl = group_incl_scan<64>(f.len);
+  s.total = min(group_last<64>(incl), (uint32_t)STEPS * 64u);
+  lds_fence();
+  st[lane] = incl - f.len;
+  p0s[lane] = f.p0;
+  if constexpr (NUMERIC) avs[lane] = f.av;
+  if (f.len && incl - f.len < SH_MAX_NPROD) marks[incl - f.len] = (uint8_t)(lane + 1u);
+  lds_fence();
+  uint32_t carry = 1u;
+  const uint32_t nsteps = (s.total + 63u) >> 6;
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {
+    s.c[u] = EMPTY_KEY;
+    s.bv[u] = 0.0;
+    s.t[u] = 0;
+    if ((uint32_t)u < nsteps) { // wave-uniform
+      const uint32_t q = (uint32_t)u * 64u + lane;
+      const bool valid = q < s.total;
+      const uint32_t mk = valid ? (uint32_t)marks[q] : 0u;
+      const uint32_t tt = max(wave_incl_max(mk), carry);
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)tt, 63);
+      const uint32_t t = tt - 1u;
+      const uint64_t p = p0s[t] + (q - st[t]);
+      if (valid) s.c[u] = B.col[p];
+      s.t[u] = t;
+      if constexpr (NUMERIC)
+        if (valid) s.bv[u] = B.val[p];
+    }
+  }
+}
+
+// ---- symbolic: number of distinct columns of the row, nothing else --------------------------------
+// LDS per wavefront: keys[S] u32 (S = 1 << log2s >= 2 * products) | walk scratch.
+template <int STEPS>
+__global__ void __launch_bounds__(256)
+    k_sym_count(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s,
+                uint32_t wpb, uint32_t rpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
+  if (w >= wpb || first64 >= nrows) return;
+  const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
+  const uint32_t S = 1u << log2s, mask = S - 1u;
+  const size_t region = (size_t)S * 4u + SH_SCRATCH;
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
+  unsigned char *scratch = smem + w * region + (size_t)S * 4u;
+  const ColMap none{nullptr, 0, 0.0};
+  ShortFetch fa;
+  ShortSet<false, STEPS> cur, nxt;
+  short_fetch<false>(A, B, m, nullptr, rows, first, lane, fa);
+  short_expand<false, STEPS>(B, none, fa, lane, scratch, 0u, cur);
+  if (first + 1u < last) short_fetch<false>(A, B, m, nullptr, rows, first + 1u, lane, fa);
+  for (uint32_t i = first; i < last; ++i) {
+    if (i + 1u < last) {
+      short_expand<false, STEPS>(B, none, fa, lane, scratch, 0u, nxt);
+      if (i + 2u < last) short_fetch<false>(A, B, m, nullptr, rows, i + 2u, lane, fa);
+    }
+    for (uint32_t j = lane * 4u; j < S; j += 256u)
+      *reinterpret_cast<uint4 *>(&keys[j]) = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+    lds_fence();
+    // the probe chains of a lane's products advance together
+    uint32_t mine = 0, h[STEPS], c[STEPS];
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      c[u] = cur.c[u];
+      h[u] = hash_slot(c[u], log2s);
+    }
+    for (;;) {
+      bool open = false;
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) {
+        if (c[u] != EMPTY_KEY) {
+          const uint32_t old = atomicCAS(&keys[h[u]], EMPTY_KEY, c[u]);
+          if (old == EMPTY_KEY) { ++mine; c[u] = EMPTY_KEY; }
+          else if (old == c[u]) c[u] = EMPTY_KEY;
+          else h[u] = (h[u] + 1u) & mask; // the table is at most half full: an empty slot comes
+          open |= c[u] != EMPTY_KEY;
+        }
+      }
+      if (!__any(open)) break;
+    }
+    const uint32_t n = group_sum<64>(mine);
+    if (lane == 0) {
+      m.nnz[cur.row] = n;
+      m.num_key[cur.row] = (uint8_t)num_key_of(m.sym_key[cur.row], n, m.hash_num_max);
+    }
+    lds_fence();
+    cur = nxt;
+  }
+}
+
+// ---- numeric: expand, sort by (column, product number), sum runs, write -------------------------------
+// PM = 1 << log2pm >= products of the row.  LDS per wavefront:
+//   tab[3 PM] u64 | prodv[PM] f64 | walk scratch.
+// 1. Every product q (numbered in the CPU loop's order: A entry after A entry, B row order inside)
+//    puts the entry (column << 32 | q) into tab[] by sorted linear probing: the home slot is a
+//    monotone function of the column (ColMap, scaled to [0, 2 * products)); a probe leaves the
+//    smaller of {slot, carried entry} in the slot (64-bit atomic min) and carries the larger on.
+//    A slot only ever decreases and an empty slot is never crossed, so at the end every run of
+//    occupied slots is ascending and the runs are ordered among themselves: the table holds the
+//    row's products sorted by column and, inside a column, in the order the CPU adds them.  No
+//    wrap-around: at most `products` entries lie past the last home slot.  The product's value goes
+//    to prodv[q].
+// 2. The table is read in slot order.  The first entry of a column sums the column's entries one
+//    after the other (they are adjacent) - the CPU's order of additions, bit for bit - and is written
+//    at the position given by the number of column starts before it.
+template <int STEPS>
+__global__ void __launch_bounds__(256)
+    k_num_short(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o, ColMap cm,
+                uint32_t log2pm, uint32_t wpb, uint32_t rpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
+  if (w >= wpb || first64 >= nrows) return;
+  const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
+  const uint32_t PM = 1u << log2pm;
+  const size_t region = (size_t)PM * 32u + SH_SCRATCH;
+  unsigned char *reg = smem + w * region;
+  unsigned long long *tab = reinterpret_cast<unsigned long long *>(reg);
+  double *prodv = reinterpret_cast<double *>(reg + (size_t)PM * 24u);
+  unsigned char *scratch = reg + (size_t)PM * 32u;
+  constexpr unsigned long long EMPTY64 = ~0ull;
+  uint32_t nz = 0;
+  ShortFetch fa;
+  ShortSet<true, STEPS> cur, nxt;
+  const double *avs = reinterpret_cast<const double *>(scratch + 768);
+  short_fetch<true>(A, B, m, o.c_ptr, rows, first, lane, fa);
+  short_expand<true, STEPS>(B, cm, fa, lane, scratch, first & 1u, cur);
+  if (first + 1u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, first + 1u, lane, fa);
+  for (uint32_t i = first; i < last; ++i) {
+    if (i + 1u < last) {
+      short_expand<true, STEPS>(B, cm, fa, lane, scratch, (i + 1u) & 1u, nxt);
+      if (i + 2u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, i + 2u, lane, fa);
+    }
+    const uint32_t total = min(cur.total, PM), n = cur.n;
+    const uint64_t off = cur.off;
+    const uint32_t H = 2u * total, T = (3u * total + 63u) & ~63u; // slots in use: a multiple of 64, <= 3 PM
+    for (uint32_t j = lane * 2u; j < T; j += 128u)
+      *reinterpret_cast<ulonglong2 *>(&tab[j]) = make_ulonglong2(EMPTY64, EMPTY64);
+    // the row's own column range stretched over the home slots
+    const double inv = cm.inv_width;
+    const double f_lo = cur.f[0] + (cur.f[1] - cur.f[0]) * ((double)(cur.cmin - ((cur.cmin >> cm.shift) << cm.shift)) * inv);
+    const double f_hi = cur.f[2] + (cur.f[3] - cur.f[2]) * ((double)(cur.cmax - ((cur.cmax >> cm.shift) << cm.shift)) * inv);
+    const double scale = (double)H / (f_hi - f_lo + 1.0);
+    unsigned long long x[STEPS];
+    uint32_t h[STEPS];
+    double fc[STEPS];
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) fc[u] = cur.c[u] != EMPTY_KEY ? colmap_eval(cm, cur.c[u]) : 0.0;
+    lds_fence();
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      x[u] = EMPTY64;
+      h[u] = 0;
+      if (cur.c[u] != EMPTY_KEY) {
+        const uint32_t q = (uint32_t)u * 64u + lane;
+        prodv[q] = __dmul_rn(avs[64u * (i & 1u) + cur.t[u]], cur.bv[u]);
+        x[u] = ((unsigned long long)cur.c[u] << 32) | q;
+        h[u] = min(H - 1u, (uint32_t)((fc[u] - f_lo) * scale));
+      }
+    }
+    // 1. sorted insertion; the chains of a lane's products advance together
+    for (;;) {
+      bool open = false;
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) {
+        if (x[u] != EMPTY64) {
+          const unsigned long long old = atomicMin(&tab[h[u]], x[u]);
+          if (old > x[u]) x[u] = old; // EMPTY64 ends the chain
+          ++h[u];
+          if (h[u] >= T) x[u] = EMPTY64; // cannot happen: at most `total` entries past the last home slot
+          open |= x[u] != EMPTY64;
+        }
+      }
+      if (!__any(open)) break;
+    }
+    lds_fence();
+    // 2. runs of equal columns, in slot order
+    uint32_t base = 0;
+    const bool plain = n == total; // no column twice: every entry is its own output
+    for (uint32_t s0 = 0; s0 < T; s0 += 64u) {
+      const uint32_t sl = s0 + lane;
+      const unsigned long long e = tab[sl];
+      const uint32_t col = (uint32_t)(e >> 32);
+      const bool occ = e != EMPTY64;
+      // a column starts where the slot before holds another column or nothing (an empty slot reads as
+      // column 0xFFFFFFFF, which no entry has)
+      const uint32_t prev_col = (sl && !plain) ? reinterpret_cast<const uint32_t *>(tab)[2u * (sl - 1u) + 1u] : EMPTY_KEY;
+      const bool start = occ && prev_col != col;
+      const uint64_t bal = __ballot(start);
+      if (start) {
+        double v = prodv[(uint32_t)e];
+        if (!plain)
+          for (uint32_t j = sl + 1u; j < T; ++j) {
+            const unsigned long long g = tab[j];
+            if ((uint32_t)(g >> 32) != col || g == EMPTY64) break;
+            v += prodv[(uint32_t)g];
+          }
+        const uint32_t pp = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (pp < n) {
+          o.c_col[off + pp] = col;
+          o.c_val[off + pp] = v;
+          nz += (v == 0.0) ? 1u : 0u;
+        }
+      }
+      base += (uint32_t)__popcll(bal);
+    }
+    lds_fence();
+    cur = nxt;
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+}
+
+// ---- column map of a B matrix: histogram over CDF_BINS column ranges, then its prefix sums ----------
+__global__ void __launch_bounds__(256)
+    k_col_hist(uint64_t nnz, const uint32_t *__restrict__ col, uint32_t shift, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_h[CDF_BINS];
+  for (uint32_t i = threadIdx.x; i < CDF_BINS; i += blockDim.x) s_h[i] = 0u;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&s_h[min(col[i] >> shift, CDF_BINS - 1u)], 1u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < CDF_BINS; i += blockDim.x)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+// one workgroup of 1024 threads, two bins per thread; cdf[b] = entries in the bins before b
+__global__ void __launch_bounds__(1024) k_col_cdf(const uint32_t *__restrict__ hist, double *__restrict__ cdf) {
+  __shared__ uint64_t s_wave[16];
+  const uint32_t i = threadIdx.x;
+  const uint64_t a = hist[2u * i], b = hist[2u * i + 1u];
+  uint64_t tot;
+  const uint64_t ex = block_excl_scan64(a + b, s_wave, &tot);
+  cdf[2u * i] = (double)ex;
+  cdf[2u * i + 1u] = (double)(ex + a);
+  if (i == 0) cdf[CDF_BINS] = (double)tot;
+}
+
+} // namespace sg

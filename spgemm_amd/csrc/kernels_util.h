@@ -138,6 +138,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- streaming copy: what this GPU's HBM delivers to a plain 16-byte-per-lane copy ------------------------
+__global__ void __launch_bounds__(256)
+    k_stream_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 // ---- B exchange helpers ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     k_row_len(uint64_t rows, const uint64_t *__restrict__ ptr, uint32_t *__restrict__ len) {

@@ -23,6 +23,8 @@ struct RowMeta {
   const uint8_t *__restrict__ gcnt;   // rows in the group led by this row (0: follower)
   const uint32_t *__restrict__ lead;  // leader of the row's group (the row itself when ungrouped)
   uint32_t hash_num_max;              // see num_key_of
+  const uint64_t *__restrict__ a_p0;  // short rows: per A entry, start of its B row ...
+  const uint32_t *__restrict__ a_len; // ... and the B row's length (written by the analysis)
 };
 
 // ---- walking the products of one row ----------------------------------------------------------

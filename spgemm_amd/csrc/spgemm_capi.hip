@@ -54,7 +54,9 @@ struct spgemm_mat {
   bool owns = false;
   int device = 0;
   uint4 *d_rowinfo = nullptr; // {min col, max col, length} per row, built on first use as B
-  size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0;
+  double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
+  uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
+  size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0, bytes_colcdf = 0;
 };
 
 struct Block {
@@ -88,6 +90,7 @@ struct spgemm_ctx {
   uint32_t slice_blocks = 0;     // workgroups of the slice kernel (0: fill the device)
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
+  uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
@@ -114,6 +117,8 @@ struct spgemm_ctx {
     uint32_t *r_cmin = nullptr, *r_cmax = nullptr, *r_nnz = nullptr;
     uint8_t *r_key = nullptr, *r_numkey = nullptr, *r_gcnt = nullptr;
     uint32_t *r_lead = nullptr;
+    uint64_t *a_p0 = nullptr;  // short rows: B row start / length per A entry
+    uint32_t *a_len = nullptr;
     uint64_t *t_off = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *blk_hist = nullptr;
@@ -253,14 +258,28 @@ static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uin
 static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   if (B->d_rowinfo) return SPGEMM_OK;
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
-  TRY(pool_alloc(ctx, (B->rows + 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
-  HIP_TRY(hipMemsetAsync(mb->d_rowinfo + B->rows, 0, sizeof(uint4), ctx->stream)); // count of unsorted rows
+  TRY(pool_alloc(ctx, (2 * B->rows + 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
+  HIP_TRY(hipMemsetAsync(mb->d_rowinfo + 2 * B->rows, 0, sizeof(uint4), ctx->stream)); // count of unsorted rows
   if (B->rows) {
     uint32_t blocks = div_up_u64(B->rows * 8, 256);
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                        mb->d_rowinfo);
     HIP_TRY(hipGetLastError());
   }
+  // column map of the short-row numeric kernel: entries of B per column range, prefix summed
+  uint32_t shift = 0;
+  while (B->cols && ((B->cols - 1) >> shift) >= CDF_BINS) ++shift;
+  mb->cdf_shift = shift;
+  const size_t cdf_bytes = align_up((CDF_BINS + 1) * sizeof(double), 256);
+  TRY(pool_alloc(ctx, cdf_bytes + CDF_BINS * sizeof(uint32_t), (void **)&mb->d_colcdf, &mb->bytes_colcdf));
+  uint32_t *hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mb->d_colcdf) + cdf_bytes);
+  HIP_TRY(hipMemsetAsync(hist, 0, CDF_BINS * sizeof(uint32_t), ctx->stream));
+  if (B->nnz) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(B->nnz, 256 * 16), 2048);
+    hipLaunchKernelGGL(k_col_hist, dim3(blocks), dim3(256), 0, ctx->stream, B->nnz, B->d_col, shift, hist);
+  }
+  hipLaunchKernelGGL(k_col_cdf, dim3(1), dim3(1024), 0, ctx->stream, hist, mb->d_colcdf);
+  HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
 
@@ -274,6 +293,13 @@ static uint32_t pick_wpb(size_t region) {
     if (waves >= best_waves) { best_waves = waves; wpb = w; }
   }
   return wpb;
+}
+
+// Rows a wavefront of the short-row kernels takes one after the other (it pipelines their loads):
+// as many as leave about 64 wavefronts of work per CU, at most short_rpw.
+static uint32_t short_rows_per_wave(const spgemm_ctx *ctx, uint32_t rows) {
+  const uint64_t waves = (uint64_t)ctx->cu_count * 64;
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->short_rpw, rows / waves));
 }
 
 // ---- LDS limits ------------------------------------------------------------------------------------
@@ -293,6 +319,8 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
   raise_lds_limit(k_sym_big);
   raise_lds_limit(k_sym_hash_wg);
+  raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
+  raise_lds_limit(k_num_short<4>); raise_lds_limit(k_num_short<SH_STEPS>);
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -328,6 +356,7 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
   ctx->cp.g_thresh0 = 6;
   ctx->cp.g_thresh1 = 12;
   ctx->cp.g_thresh2 = 24;
+  ctx->cp.short_max_nprod = SH_MAX_NPROD;
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   // a failure below releases whatever was created so far (spgemm_destroy copes with a partial context)
   const char *what = "hipStreamCreate";
@@ -424,6 +453,43 @@ extern "C" int spgemm_internal_pool_alloc(spgemm_ctx *ctx, size_t bytes, void **
 }
 extern "C" void spgemm_internal_pool_release(spgemm_ctx *ctx, void *p, size_t got) { pool_release(ctx, p, got); }
 
+// Measured rate of a streaming copy of `bytes` bytes (read + write counted, GB/s, best of `reps`):
+// the achievable HBM rate the roofline figures are put next to.  Used by the benchmark only.
+extern "C" int spgemm_internal_stream_copy_rate(spgemm_ctx *ctx, size_t bytes, int reps, double *gbs) {
+  if (!ctx || !gbs || bytes < 4096 || reps < 1) return fail(SPGEMM_ERR_INVALID, "bad argument");
+  TRY(set_device(ctx));
+  void *src = nullptr, *dst = nullptr;
+  size_t gs = 0, gd = 0;
+  TRY(pool_alloc(ctx, bytes, &src, &gs));
+  int rc = pool_alloc(ctx, bytes, &dst, &gd);
+  if (rc != SPGEMM_OK) { pool_release(ctx, src, gs); return rc; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipMemsetAsync(src, 1, bytes, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
+  float best = 0.f;
+  const uint64_t n16 = bytes / 16;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(n16, 256), (uint64_t)ctx->cu_count * 16);
+  for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) { // first pass warms up
+    e = hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)src, (uint4 *)dst, n16);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(ctx->stream);
+  pool_release(ctx, src, gs);
+  pool_release(ctx, dst, gd);
+  if (e != hipSuccess) return fail(SPGEMM_ERR_HIP, "stream copy failed: %s", hipGetErrorString(e));
+  *gbs = best > 0.f ? 2.0 * (double)(n16 * 16) / ((double)best * 1e-3) / 1e9 : 0.0;
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_synchronize(spgemm_ctx *ctx) {
   if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
   TRY(set_device(ctx));
@@ -449,6 +515,12 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     ctx->cp.g_thresh1 = (uint32_t)value;
   } else if (n == "g_thresh2") {
     ctx->cp.g_thresh2 = (uint32_t)value;
+  } else if (n == "short_max_nprod") {
+    if (value > SH_MAX_NPROD) return fail(SPGEMM_ERR_INVALID, "short_max_nprod is at most %u", SH_MAX_NPROD);
+    ctx->cp.short_max_nprod = (uint32_t)value;
+  } else if (n == "short_rpw") {
+    if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "short_rpw must be 1..4096");
+    ctx->short_rpw = (uint32_t)value;
   } else if (n == "flat_walk") {
     ctx->flat_walk = value != 0;
   } else if (n == "row_groups") {
@@ -635,8 +707,10 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
   if (m->d_rowinfo) {
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a queued multiply may still read the row info
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
+    pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
     m->d_rowinfo = nullptr;
-    m->bytes_rowinfo = 0;
+    m->d_colcdf = nullptr;
+    m->bytes_rowinfo = m->bytes_colcdf = 0;
   }
   return SPGEMM_OK;
 }
@@ -649,6 +723,7 @@ extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
   if (m->d_rowinfo) {
     (void)hipStreamSynchronize(ctx->stream);
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
+    pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
   }
   if (m->owns) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -757,6 +832,8 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   need += align_up(hist_n * 4, 256) + align_up((hist_n + 1) * 8, 256); // partition histogram + scan
   need += align_up(((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2) * 8, 256); // scan partials
   need += align_up((MAX_BINS + 1) * 8, 256) + NPROD_SLOTS * 8 + 256 + 256; // bin_off, counters
+  const bool short_aux = ctx->cp.short_max_nprod > 0;
+  if (short_aux) need += align_up(A->nnz * 8, 256) + align_up(A->nnz * 4, 256); // short rows: B row start and length per A entry
   TRY(grow(ctx, ctx->arena, need));
   ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
   uint32_t *r_cmin = ar.take<uint32_t>(rows), *r_cmax = ar.take<uint32_t>(rows);
@@ -775,6 +852,8 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint64_t *total_nprod = ar.take<uint64_t>(NPROD_SLOTS);
   unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32));
   uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
+  uint64_t *a_p0 = short_aux ? ar.take<uint64_t>(A->nnz) : nullptr;
+  uint32_t *a_len = short_aux ? ar.take<uint32_t>(A->nnz) : nullptr;
   ctx->r_nprod_prof = r_nprod;
   ctx->plan_gcnt = r_gcnt;
   ctx->launches.clear();
@@ -786,7 +865,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
   HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
 
-  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same};
+  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same, a_p0, a_len};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   if (max_long > 1 || A->nnz > ctx->long_len)
@@ -803,7 +882,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (SYM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(hc->nprod_parts, total_nprod, NPROD_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(&hc->b_unsorted, &B->d_rowinfo[B->rows].x, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const bool b_sorted = hc->b_unsorted == 0;
   st.nprod = 0;
@@ -819,7 +898,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   // kernel (whose largest tables leave room for two wavefronts per CU) for the slice kernel
   const uint32_t hash_num_max = (b_sorted && ctx->big_rows) ? ctx->hash_num_slice : 4096u;
   RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey, r_gcnt, r_lead,
-             hash_num_max};
+             hash_num_max, a_p0, a_len};
 
   for (int key = 0; key < SYM_NBINS; ++key) {
     uint64_t cnt64 = boff[key + 1] - boff[key];
@@ -839,6 +918,19 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
       uint32_t log2s = 7 + tier;
+      if ((key & 3) == 0) { // short rows: count only
+        const size_t region = ((size_t)4 << log2s) + SH_SCRATCH;
+        const uint32_t wpb = pick_wpb(region);
+        st.rows_hash += cnt;
+        TRY(prof_begin(ctx, 0, 1, 1, cnt, log2s, 0, region * wpb, rows_bin));
+        const uint32_t rpw = short_rows_per_wave(ctx, cnt);
+        // tier t holds rows of at most 64 << t products: up to 4 steps of 64 products, or 8
+        hipLaunchKernelGGL(tier <= 2 ? k_sym_count<4> : k_sym_count<SH_STEPS>, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
+                           dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s, wpb, rpw);
+        HIP_TRY(hipGetLastError());
+        TRY(prof_end(ctx));
+        continue;
+      }
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = pick_wpb(region);
@@ -889,6 +981,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.r_cmin = r_cmin; pl.r_cmax = r_cmax; pl.r_nnz = r_nnz;
   pl.r_key = r_key; pl.r_numkey = r_numkey; pl.t_off = t_off; pl.perm = perm;
   pl.r_gcnt = r_gcnt; pl.r_lead = r_lead;
+  pl.a_p0 = a_p0; pl.a_len = a_len;
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
   pl.b_sorted = b_sorted;
@@ -934,7 +1027,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
   RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
-             pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u};
+             pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u, pl.a_p0, pl.a_len};
   NumOut no{d_row_ptr, d_col, d_val, zero_count};
   const size_t lds_max = 160 * 1024;
 
@@ -956,6 +1049,16 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       hipLaunchKernelGGL(tier == 0 ? k_num_window_grp<0> : tier == 1 ? k_num_window_grp<1> : k_num_window_grp<2>,
                          dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb);
+    } else if (key >= NUM_HASH0 && key < NUM_GLOBAL && (key & 3) == 0) { // short rows
+      const uint32_t log2pm = 6 + ((uint32_t)(key - NUM_HASH0) >> 2);
+      const size_t region = ((size_t)32 << log2pm) + SH_SCRATCH;
+      if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
+      const uint32_t wpb = pick_wpb(region);
+      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift)};
+      TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
+      const uint32_t rpw = short_rows_per_wave(ctx, cnt);
+      hipLaunchKernelGGL(log2pm <= 8 ? k_num_short<4> : k_num_short<SH_STEPS>, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
+                         dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, cm, log2pm, wpb, rpw);
     } else if (key < NUM_GLOBAL) {
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
       const bool window = key < NUM_HASH0;
@@ -1270,7 +1373,7 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
   HIP_TRY(hipMemsetAsync(total, 0, NPROD_SLOTS * 8, ctx->stream));
   uint8_t *same = ar.take<uint8_t>(rows);
-  AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count, same};
+  AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count, same, nullptr, nullptr};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   hipLaunchKernelGGL(k_analyze_long, dim3(256), dim3(256), 0, ctx->stream, A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp);

@@ -572,8 +572,7 @@ def bench_main(args):
             dom = max(num, key=lambda l: l["ms"])
             b = bench_mod.algorithmic_bytes(dom["nnz_a"], dom["nprod"], dom["nnz_c"], dom["rows"])
             achieved = b / (dom["ms"] * 1e-3) / 1e9
-            kname = {"window_groups": "k_num_window_grp", "big_rows": "k_num_slice"}.get(
-                dom["path"], f"k_num_{dom['path']}<{dom['lanes']}>")
+            kname = bench_mod.kernel_name(dom)
             roofline = {"bound": "hbm", "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                         "kernel_ms": dom["ms"], "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b,
