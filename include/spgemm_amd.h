@@ -243,7 +243,10 @@ int spgemm_mat_relabel_columns(spgemm_ctx *ctx, const spgemm_mat *M, const uint3
  *  section_nnz:  HOST array of n_sections entries = stored entries per row section of M.
  *  pack:         gathers the row lengths / col_idx / val of the sections whose bit is set in
  *                bitmap_words (HOST) into caller device buffers, sections in ascending order;
- *                returns rows and entries written.
+ *                returns rows and entries written.  The copies are QUEUED on the context's stream
+ *                (the counts come from a host copy of the row pointer cached on the handle): the
+ *                call does not wait for them, later work on the stream or spgemm_synchronize does.
+ *  assemble:     with nnz_out == NULL it is queued likewise.
  *  assemble:     builds, on the receiving side, the row pointer of a B that has all `rows` rows
  *                where only the sections set in bitmap_words are present (others empty), from
  *                the concatenated row lengths of the present sections; col_idx/val of that B

@@ -398,15 +398,15 @@ class Context:
         return r.value, n.value
 
     def assemble_row_ptr(self, rows: int, n_sections: int, bits: np.ndarray, d_row_len_concat: int, n_row_len: int,
-                         d_row_ptr_out: int, noalloc: bool = False) -> int:
-        """noalloc=True: the variant that allocates nothing (at most 2^22 rows)."""
+                         d_row_ptr_out: int, noalloc: bool = False, want_nnz: bool = True) -> Optional[int]:
+        """noalloc=True: the variant that allocates nothing (at most 2^22 rows).  want_nnz=False: the
+        call is only queued on the stream (nothing is read back) and returns None."""
         words = bitmap_words(bits)
         n = ctypes.c_uint64()
         fn = load().spgemm_assemble_row_ptr_noalloc if noalloc else load().spgemm_assemble_row_ptr
-        _check(fn(self.handle, rows, n_sections, _np_ptr(words),
-                                              ctypes.c_void_p(d_row_len_concat), n_row_len,
-                                              ctypes.c_void_p(d_row_ptr_out), ctypes.byref(n)))
-        return n.value
+        _check(fn(self.handle, rows, n_sections, _np_ptr(words), ctypes.c_void_p(d_row_len_concat), n_row_len,
+                  ctypes.c_void_p(d_row_ptr_out), ctypes.byref(n) if want_nnz else None))
+        return n.value if want_nnz else None
 
 
 # -- host-only entry points (no GPU needed) ------------------------------------------------------------

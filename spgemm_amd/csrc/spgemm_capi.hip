@@ -57,6 +57,10 @@ struct spgemm_mat {
   double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
   uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
   size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0, bytes_colcdf = 0;
+  // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
+  std::vector<uint64_t> h_ptr;  // host copy of the row pointer
+  uint32_t *d_rowlen = nullptr; // row lengths as uint32 (what travels in the exchange)
+  size_t bytes_rowlen = 0;
 };
 
 struct Block {
@@ -126,6 +130,10 @@ struct spgemm_ctx {
     unsigned long long *zero_count = nullptr;
     uint32_t pblocks = 0;
     uint64_t nnz_structural = 0;
+    // read back together with nnz_structural (one host round trip after the symbolic phase)
+    bool num_ready = false;          // the three fields below are valid
+    uint64_t num_boff[MAX_BINS + 1]; // start of every numeric bin in `perm`
+    uint32_t max_len_big = 0;        // longest A row among the big rows
     bool b_sorted = false; // every B row has strictly increasing columns
   } plan;
   size_t arena_used = 0;
@@ -266,7 +274,14 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
                        mb->d_rowinfo);
     HIP_TRY(hipGetLastError());
   }
-  // column map of the short-row numeric kernel: entries of B per column range, prefix summed
+  return SPGEMM_OK;
+}
+
+// Column map of the short-row numeric kernel (entries of B per column range, prefix summed): built
+// when the first launch of that kernel needs it, kept on the handle like the row info.
+static int ensure_colcdf(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_colcdf) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
   uint32_t shift = 0;
   while (B->cols && ((B->cols - 1) >> shift) >= CDF_BINS) ++shift;
   mb->cdf_shift = shift;
@@ -704,10 +719,17 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
   if (!ctx || !m) return fail(SPGEMM_ERR_INVALID, "NULL argument");
   TRY(set_device(ctx));
   if (ctx->plan.valid && (ctx->plan.A == m || ctx->plan.B == m)) ctx->plan.valid = false;
+  if (m->d_rowlen) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
+    m->d_rowlen = nullptr;
+    m->bytes_rowlen = 0;
+  }
+  m->h_ptr.clear();
   if (m->d_rowinfo) {
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a queued multiply may still read the row info
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
-    pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+    if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
     m->d_rowinfo = nullptr;
     m->d_colcdf = nullptr;
     m->bytes_rowinfo = m->bytes_colcdf = 0;
@@ -723,7 +745,11 @@ extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
   if (m->d_rowinfo) {
     (void)hipStreamSynchronize(ctx->stream);
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
-    pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+    if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+  }
+  if (m->d_rowlen) {
+    (void)hipStreamSynchronize(ctx->stream);
+    pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
   }
   if (m->owns) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -989,6 +1015,44 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   return SPGEMM_OK;
 }
 
+// Queued right behind the symbolic phase: rows partitioned by numeric bin, counters zeroed, longest
+// big A row; the bin offsets, that length and the structural nnz are copied to the pinned buffer.
+// numeric_counts_ready() is called after the caller's stream synchronisation and moves them into
+// the plan: ONE host round trip between the symbolic and the numeric phase.
+static int numeric_prepare(spgemm_ctx *ctx, const spgemm_mat *A, const uint64_t *d_row_ptr) {
+  spgemm_ctx::Plan &pl = ctx->plan;
+  pl.num_ready = false;
+  const uint32_t rows = (uint32_t)A->rows;
+  HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
+  hc->total_a = 0;
+  hc->max_len_big = 0;
+  memset(hc->bin_off, 0, sizeof(hc->bin_off));
+  if (rows == 0) return SPGEMM_OK;
+  HIP_TRY(hipMemcpyAsync(&hc->total_a, d_row_ptr + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PartScratch ps{pl.pblocks, pl.blk_hist, pl.blk_off, pl.partial};
+  TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, pl.perm, pl.bin_off));
+  HIP_TRY(hipMemsetAsync(pl.zero_count, 0, 256, ctx->stream));
+  // zero_count[1]: work counter of the slice kernel; zero_count[2] (low word): longest big A row
+  uint32_t *max_len_big = reinterpret_cast<uint32_t *>(pl.zero_count + 2);
+  if (pl.b_sorted && ctx->big_rows) {
+    hipLaunchKernelGGL(k_slice_maxlen, dim3(std::min<uint32_t>(div_up_u64(rows, 256), 2048)), dim3(256), 0, ctx->stream,
+                       rows, A->d_ptr, pl.r_numkey, max_len_big);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&hc->max_len_big, max_len_big, 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(hc->bin_off, pl.bin_off, (NUM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  return SPGEMM_OK;
+}
+static uint64_t numeric_counts_ready(spgemm_ctx *ctx) { // after the stream has been synchronised
+  spgemm_ctx::Plan &pl = ctx->plan;
+  const HostCounts *hc = reinterpret_cast<const HostCounts *>(ctx->h_pinned);
+  memcpy(pl.num_boff, hc->bin_off, (NUM_NBINS + 1) * 8);
+  pl.max_len_big = hc->max_len_big;
+  pl.nnz_structural = hc->total_a;
+  pl.num_ready = true;
+  return pl.nnz_structural;
+}
+
 // numeric phase; needs ctx->plan from run_symbolic on the same operands.
 static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B, uint64_t *d_row_ptr,
                        uint32_t *d_col, double *d_val, uint64_t nnz_structural, uint64_t *nnz_final,
@@ -1003,26 +1067,14 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
     return SPGEMM_OK;
   }
   uint32_t *perm = pl.perm;
-  uint64_t *partial = pl.partial, *bin_off = pl.bin_off;
+  uint64_t *partial = pl.partial;
   unsigned long long *zero_count = pl.zero_count;
-  PartScratch ps{pl.pblocks, pl.blk_hist, pl.blk_off, pl.partial};
-  TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, perm, bin_off));
-  HIP_TRY(hipMemsetAsync(zero_count, 0, 256, ctx->stream));
-  HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
-  // zero_count[1]: work counter of the slice kernel; zero_count[2] (low word): longest big A row
-  uint32_t *max_len_big = reinterpret_cast<uint32_t *>(zero_count + 2);
+  if (!pl.num_ready) return fail(SPGEMM_ERR_STATE, "internal: the numeric bins were not read back");
   const bool slices = pl.b_sorted && ctx->big_rows;
-  if (slices) {
-    hipLaunchKernelGGL(k_slice_maxlen, dim3(std::min<uint32_t>(div_up_u64(rows, 256), 2048)), dim3(256), 0, ctx->stream,
-                       rows, A->d_ptr, pl.r_numkey, max_len_big);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&hc->max_len_big, max_len_big, 4, hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (NUM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const uint64_t list_cap = slices ? std::max<uint32_t>(hc->max_len_big, 64) : 0;
+  HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
+  const uint64_t list_cap = slices ? std::max<uint32_t>(pl.max_len_big, 64) : 0;
   uint64_t boff[NUM_NBINS + 1];
-  memcpy(boff, hc->bin_off, sizeof(boff));
+  memcpy(boff, pl.num_boff, sizeof(boff));
   HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
@@ -1054,6 +1106,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       const size_t region = ((size_t)32 << log2pm) + SH_SCRATCH;
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       const uint32_t wpb = pick_wpb(region);
+      TRY(ensure_colcdf(ctx, B));
       ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift)};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
@@ -1225,11 +1278,11 @@ extern "C" int spgemm_multiply(spgemm_ctx *ctx, const spgemm_mat *A, const spgem
   int rc = pool_alloc(ctx, (A->rows + 1) * 8, (void **)&C->d_ptr, &C->bytes_ptr);
   if (rc == SPGEMM_OK) rc = run_symbolic(ctx, A, B, C->d_ptr);
   uint64_t nnz_s = 0;
+  if (rc == SPGEMM_OK) rc = numeric_prepare(ctx, A, C->d_ptr);
   if (rc == SPGEMM_OK) {
-    hipError_t e = hipMemcpyAsync(ctx->h_pinned, C->d_ptr + A->rows, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "reading nnz failed: %s", hipGetErrorString(e));
-    nnz_s = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
+    else nnz_s = numeric_counts_ready(ctx);
   }
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz_s * 4, (void **)&C->d_col, &C->bytes_col);
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz_s * 8, (void **)&C->d_val, &C->bytes_val);
@@ -1253,10 +1306,9 @@ extern "C" int spgemm_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgem
   if (!ctx || !A || !B || !d_row_ptr || !nnz_structural) return fail(SPGEMM_ERR_INVALID, "NULL argument");
   TRY(set_device(ctx));
   TRY(run_symbolic(ctx, A, B, d_row_ptr));
-  HIP_TRY(hipMemcpyAsync(ctx->h_pinned, d_row_ptr + A->rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  TRY(numeric_prepare(ctx, A, d_row_ptr));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  *nnz_structural = *reinterpret_cast<uint64_t *>(ctx->h_pinned);
-  ctx->plan.nnz_structural = *nnz_structural;
+  *nnz_structural = numeric_counts_ready(ctx);
   return SPGEMM_OK;
 }
 
@@ -1516,9 +1568,17 @@ static void section_rows(uint64_t total_rows, uint32_t n_sections, uint32_t s, u
   *r1 = (s == n_sections - 1) ? total_rows : sh * (s + 1);
 }
 
-static int fetch_row_ptr(spgemm_ctx *ctx, const spgemm_mat *M, std::vector<uint64_t> &ptr) {
-  ptr.resize(M->rows + 1);
-  HIP_TRY(hipMemcpyAsync(ptr.data(), M->d_ptr, (M->rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+// Host copy of the row pointer and device array of the row lengths, cached on the handle.
+static int ensure_section_cache(spgemm_ctx *ctx, const spgemm_mat *M) {
+  spgemm_mat *m = const_cast<spgemm_mat *>(M);
+  if (m->h_ptr.size() == M->rows + 1 && (m->d_rowlen || M->rows == 0)) return SPGEMM_OK;
+  m->h_ptr.resize(M->rows + 1);
+  if (M->rows && !m->d_rowlen) TRY(pool_alloc(ctx, M->rows * 4, (void **)&m->d_rowlen, &m->bytes_rowlen));
+  if (M->rows) {
+    hipLaunchKernelGGL(k_row_len, dim3(div_up_u64(M->rows, 256)), dim3(256), 0, ctx->stream, M->rows, M->d_ptr, m->d_rowlen);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(m->h_ptr.data(), M->d_ptr, (M->rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return SPGEMM_OK;
 }
@@ -1529,8 +1589,8 @@ extern "C" int spgemm_section_nnz(spgemm_ctx *ctx, const spgemm_mat *M, uint32_t
   if (first_row + M->rows > total_rows) return fail(SPGEMM_ERR_INVALID, "row block exceeds total_rows");
   if (total_rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "total_rows / n_sections == 0");
   TRY(set_device(ctx));
-  std::vector<uint64_t> ptr;
-  TRY(fetch_row_ptr(ctx, M, ptr));
+  TRY(ensure_section_cache(ctx, M));
+  const std::vector<uint64_t> &ptr = M->h_ptr;
   for (uint32_t s = 0; s < n_sections; ++s) {
     uint64_t r0, r1;
     section_rows(total_rows, n_sections, s, &r0, &r1);
@@ -1549,16 +1609,11 @@ extern "C" int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32
   if (first_row + M->rows > total_rows) return fail(SPGEMM_ERR_INVALID, "row block exceeds total_rows");
   if (total_rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "total_rows / n_sections == 0");
   TRY(set_device(ctx));
-  ctx->plan.valid = false;
-  std::vector<uint64_t> ptr;
-  TRY(fetch_row_ptr(ctx, M, ptr));
-  // row lengths of the whole block, once
-  TRY(grow(ctx, ctx->arena, align_up(M->rows * 4 + 4, 256)));
-  uint32_t *d_len = reinterpret_cast<uint32_t *>(ctx->arena.p);
-  if (M->rows) {
-    hipLaunchKernelGGL(k_row_len, dim3(div_up_u64(M->rows, 256)), dim3(256), 0, ctx->stream, M->rows, M->d_ptr, d_len);
-    HIP_TRY(hipGetLastError());
-  }
+  // the host copy of the row pointer and the row lengths are cached on the handle: after the first
+  // call everything below is queued on the stream and the call returns without waiting for it
+  TRY(ensure_section_cache(ctx, M));
+  const std::vector<uint64_t> &ptr = M->h_ptr;
+  const uint32_t *d_len = M->d_rowlen;
   uint64_t rows_w = 0, nnz_w = 0;
   // adjacent selected sections are copied as one run
   uint32_t s = 0;
@@ -1583,7 +1638,6 @@ extern "C" int spgemm_pack_sections(spgemm_ctx *ctx, const spgemm_mat *M, uint32
     }
     s = e + 1;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
   *rows_out = rows_w;
   *nnz_out = nnz_w;
   return SPGEMM_OK;

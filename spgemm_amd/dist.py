@@ -193,11 +193,17 @@ def _all_reduce(t, op=None, group=None):
 
 
 class SectionExchange:
-    """All-to-all of B row sections.  Holds this rank's B block as torch tensors and, from the
-    gathered bitmaps and the global per-section entry counts, the split sizes of the collective.
-    `run()` returns (row_ptr int64[n+1], col int32[nnz], val float64[nnz]) of the local B."""
+    """All-to-all of B row sections.  Holds this rank's B block and, from the gathered bitmaps and
+    the global per-section entry counts, the split sizes of the collective.
+    `run()` returns (row_ptr int64[n+1], col int32[nnz], val float64[nnz]) of the local B.
 
-    def __init__(self, ops: RankOperands, n_sections: int, bitmaps: np.ndarray, device, group=None, share=None):
+    With a context (`ctx`, a GPU) the sections are packed by spgemm_pack_sections and the row pointer
+    of the received B is built by spgemm_assemble_row_ptr (the allocation-free variant when B has at
+    most 2^22 rows): the same device helpers the C++ driver uses, all queued on the context's stream,
+    in buffers allocated once.  Without one (the CPU plumbing tests over gloo) torch does both."""
+
+    def __init__(self, ops: RankOperands, n_sections: int, bitmaps: np.ndarray, device, group=None, share=None,
+                 ctx=None):
         """share: another SectionExchange over the same B block, whose device copies of the block
         are used instead of making new ones (several exchanges with different bitmaps)."""
         import torch
@@ -205,17 +211,26 @@ class SectionExchange:
         self.torch, self.dist, self.group = torch, dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.n, self.N, self.device = ops.n, n_sections, device
+        self.first_row = ops.first_row
+        self.ctx = ctx
         self.bitmaps = np.asarray(bitmaps, dtype=bool)            # [world, N]
         assert self.bitmaps.shape == (self.world, n_sections)
         self.sb = section_bounds(ops.n, n_sections)
         self.ob = section_owner_bounds(n_sections, self.world)
         blk = ops.B_block
         if share is not None:
-            self.row_len, self.col, self.val = share.row_len, share.col, share.val
+            self.row_len, self.col, self.val, self.dB = share.row_len, share.col, share.val, share.dB
         else:
             self.row_len = torch.from_numpy(np.diff(blk.row_ptr.astype(np.int64)).astype(np.int32)).to(device)
             self.col = torch.from_numpy(blk.col_idx.view(np.int32).copy()).to(device)
             self.val = torch.from_numpy(blk.val.copy()).to(device)
+            self.dB = None
+            if ctx is not None:
+                self.blk_ptr = torch.from_numpy(blk.row_ptr.astype(np.int64)).to(device)
+                torch.cuda.synchronize(device)
+                self.dB = ctx.wrap_device(blk.rows, blk.cols, blk.nnz, self.blk_ptr.data_ptr(), self.col.data_ptr(),
+                                          self.val.data_ptr(), validate=False,
+                                          keepalive=(self.blk_ptr, self.col, self.val))
         # entries per section, globally: every section is owned by exactly one rank
         my_lo, my_hi = int(self.ob[self.rank]), int(self.ob[self.rank + 1])
         rp = blk.row_ptr.astype(np.int64)
@@ -265,6 +280,14 @@ class SectionExchange:
                                       if d != self.rank)
         # what this rank would send if every peer took all of its sections (no bitmap)
         self.bytes_sent_without_drop = (self.world - 1) * (4 * int(blk.rows) + 12 * int(blk.nnz))
+        if self.dB is not None:  # send / receive buffers of the device path, allocated once
+            self.buf_send = (torch.empty(sum(self.send_rows), dtype=torch.int32, device=device),
+                             torch.empty(sum(self.send_nnz), dtype=torch.int32, device=device),
+                             torch.empty(sum(self.send_nnz), dtype=torch.float64, device=device))
+            self.buf_recv = (torch.empty(sum(self.recv_rows), dtype=torch.int32, device=device),
+                             torch.empty(sum(self.recv_nnz), dtype=torch.int32, device=device),
+                             torch.empty(sum(self.recv_nnz), dtype=torch.float64, device=device),
+                             torch.empty(self.n + 1, dtype=torch.int64, device=device))
 
     def _pack(self, src, runs_key: int):
         torch = self.torch
@@ -276,7 +299,41 @@ class SectionExchange:
             return src[:0]
         return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
 
+    def _run_device(self):
+        """Pack with spgemm_pack_sections, exchange, rebuild the row pointer with
+        spgemm_assemble_row_ptr; everything is queued on the context's stream (which must be
+        torch's current stream: the collectives are ordered on it).  The result lives in this object's
+        receive buffers until its next run."""
+        torch, dist = self.torch, self.dist
+        send_len, send_col, send_val = self.buf_send
+        ro = zo = 0
+        for d in range(self.world):
+            if self.send_rows[d]:
+                r, z = self.ctx.pack_sections(self.dB, self.N, self.first_row, self.n, self.bitmaps[d],
+                                              send_len.data_ptr() + 4 * ro, send_col.data_ptr() + 4 * zo,
+                                              send_val.data_ptr() + 8 * zo)
+                assert (r, z) == (self.send_rows[d], self.send_nnz[d])
+                ro += r
+                zo += z
+        recv_len, recv_col, recv_val, row_ptr = self.buf_recv
+        if self.staged:
+            h = [x.cpu() for x in (send_len, send_col, send_val)]
+            o = [torch.empty_like(x, device="cpu") for x in (recv_len, recv_col, recv_val)]
+            dist.all_to_all_single(o[0], h[0], self.recv_rows, self.send_rows, group=self.group)
+            dist.all_to_all_single(o[1], h[1], self.recv_nnz, self.send_nnz, group=self.group)
+            dist.all_to_all_single(o[2], h[2], self.recv_nnz, self.send_nnz, group=self.group)
+            recv_len.copy_(o[0]); recv_col.copy_(o[1]); recv_val.copy_(o[2])
+        else:
+            dist.all_to_all_single(recv_len, send_len, self.recv_rows, self.send_rows, group=self.group)
+            dist.all_to_all_single(recv_col, send_col, self.recv_nnz, self.send_nnz, group=self.group)
+            dist.all_to_all_single(recv_val, send_val, self.recv_nnz, self.send_nnz, group=self.group)
+        self.ctx.assemble_row_ptr(self.n, self.N, self.bitmaps[self.rank], recv_len.data_ptr(), int(recv_len.numel()),
+                                  row_ptr.data_ptr(), noalloc=self.n <= (1 << 22), want_nnz=False)
+        return row_ptr, recv_col, recv_val
+
     def run(self):
+        if self.dB is not None:
+            return self._run_device()
         torch, dist = self.torch, self.dist
         send_len = self._pack(self.row_len, 0)
         send_col = self._pack(self.col, 1)
@@ -396,6 +453,12 @@ class DistSpgemm:
             raise ValueError("stages must be at least 1")
         self.n_stages = int(stages)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.n_stages > 1 else None
+        # the exchange's device helpers run on a context of their own when the exchange has its own
+        # stream (pipelined schedule); else on the multiply's context and stream
+        self.xctx = self.ctx
+        if self.comm_stream is not None:
+            self.xctx = capi.Context(device_index)
+            self.xctx.set_stream(self.comm_stream.cuda_stream)
         # every rank cuts its rows the same way (equal shares), so that all ranks issue the same
         # sequence of collectives
         cuts = [(ap.rows * s) // self.n_stages for s in range(self.n_stages + 1)]
@@ -412,7 +475,8 @@ class DistSpgemm:
             share = self.exchange_stage[0] if self.exchange_stage else None
             self.dA_stage.append(dA)
             self.bitmap_stage.append(bits)
-            self.exchange_stage.append(SectionExchange(self.ops, n_sections, bitmaps, self.device, group, share=share))
+            self.exchange_stage.append(SectionExchange(self.ops, n_sections, bitmaps, self.device, group, share=share,
+                                                       ctx=self.xctx))
         self.dA = self.dA_stage[0]
         self.bitmap = np.logical_or.reduce(self.bitmap_stage)      # sections this rank needs at all
         self.bitmaps = self.exchange_stage[0].bitmaps
@@ -493,6 +557,10 @@ class DistSpgemm:
             C.free()
         for dA in self.dA_stage:
             dA.free()
+        if self.exchange_stage and self.exchange_stage[0].dB is not None:
+            self.exchange_stage[0].dB.free()
+        if self.xctx is not self.ctx:
+            self.xctx.close()
         self.ctx.close()
 
 

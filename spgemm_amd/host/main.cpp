@@ -22,6 +22,7 @@
 #include <filesystem>
 #include <iostream>
 #include <memory>
+#include <thread>
 
 static void write_to_file(const std::string &name, const std::string &path) {
   std::ofstream f(path);
@@ -164,20 +165,40 @@ int main(int argc, char **argv) {
       for (int d = 0; d < n_nodes; ++d) sizes_from[d][r] = s[d];
     }
 
-    for (int i = 0; i < n_warmup; ++i)
-      for (int r = 0; r < n_nodes; ++r) { mult[r]->reset(); mult[r]->gemm(sizes_from[r], 0); }
-    for (int r = 0; r < n_nodes; ++r) measure::Measure::get_instance(r)->reset_bytes();
-
+    // One host thread per rank, as the reference's ranks are processes that run at the same time
+    // (src/main.cpp:336-356): warm-up runs, then the timed runs; every run starts behind a barrier
+    // (the reference's communication::sync_start_time).
+    for (int r = 0; r < n_nodes; ++r) { measure::Measure::get_instance(r); mult[r]->prepare(); }
     std::cout << "STARTING COMPUTATION" << std::endl;
-    for (int i = 0; i < n_runs; ++i) {
-      for (int r = 0; r < n_nodes; ++r) mult[r]->reset();
-      for (int r = 0; r < n_nodes; ++r) {
-        measure_point(r, measure::gemm, measure::MeasurementEvent::START);
-        mult[r]->gemm(sizes_from[r], 0);
-        measure_point(r, measure::gemm, measure::MeasurementEvent::END);
-        measure::Measure::get_instance(r)->flush_bytes();
+    std::vector<std::string> failure(n_nodes);
+    auto rank_main = [&](int r) {
+      try {
+        for (int i = 0; i < n_warmup + n_runs; ++i) {
+          if (i == n_warmup) measure::Measure::get_instance(r)->reset_bytes();
+          mult[r]->reset();
+          world.barrier();
+          if (i >= n_warmup) measure_point(r, measure::gemm, measure::MeasurementEvent::START);
+          mult[r]->gemm(sizes_from[r], 0);
+          if (i >= n_warmup) {
+            measure_point(r, measure::gemm, measure::MeasurementEvent::END);
+            measure::Measure::get_instance(r)->flush_bytes();
+          }
+        }
+      } catch (const std::exception &e) {
+        failure[r] = e.what();
+        std::cerr << "rank " << r << ": " << e.what() << std::endl;
+        std::exit(1); // the other ranks wait in a barrier: end the process, as MPI_Abort would
       }
+    };
+    const auto t_start = std::chrono::steady_clock::now();
+    {
+      std::vector<std::thread> threads;
+      for (int r = 0; r < n_nodes; ++r) threads.emplace_back(rank_main, r);
+      for (auto &t : threads) t.join();
     }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    printf("ranks %d: %d runs (%d warm-up) in %.3f ms wall, %.3f ms per run\n", n_nodes, n_warmup + n_runs, n_warmup, wall_ms,
+           wall_ms / std::max(1, n_warmup + n_runs));
     measure_point(0, measure::global, measure::MeasurementEvent::END);
 
     double nprod = 0, ms = 0;

@@ -13,6 +13,8 @@
 #include "measure.hpp"
 #include "partition.hpp"
 
+#include <barrier>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -49,14 +51,17 @@ class HipSpgemm;
 }
 
 namespace communication {
-// Stand-in for MPI_COMM_WORLD inside one process.
+// Stand-in for MPI_COMM_WORLD inside one process: the ranks are host threads (one per rank, as
+// the reference's ranks are processes, src/main.cpp:35-45), barrier() is MPI_Barrier.
 struct World {
   int n_nodes = 0;
   std::vector<spgemm_ctx *> ctx;          // one per rank (ranks may share a GPU)
   std::vector<mults::HipSpgemm *> ops;    // registered by the operators
-  explicit World(int n, int n_gpus) : n_nodes(n), ctx(n, nullptr), ops(n, nullptr) {
+  std::unique_ptr<std::barrier<>> bar;
+  explicit World(int n, int n_gpus) : n_nodes(n), ctx(n, nullptr), ops(n, nullptr), bar(new std::barrier<>(n)) {
     for (int r = 0; r < n; ++r) HOST_TRY(spgemm_create(r % n_gpus, &ctx[r]));
   }
+  void barrier() { bar->arrive_and_wait(); }
   ~World() {
     for (auto c : ctx) spgemm_destroy(c);
   }
@@ -136,6 +141,15 @@ class HipSpgemm : public MatrixMultiplication {
   std::vector<uint64_t> sec_nnz;       // entries of each of MY sections (index: global section id)
   std::vector<uint64_t> sec_blob_size; // reference blob size of each of my sections
   midx_t a_height = 0;
+  // exchange buffers, allocated once by prepare() (the reference allocates its receive buffers inside
+  // every gemm, src/mults/drop_parallel.cpp:65-68): what I receive (= the arrays of my local B) and,
+  // per destination, what I send
+  struct Triple { void *len = nullptr, *col = nullptr, *val = nullptr; uint64_t rows = 0, nnz = 0; };
+  Triple recv;
+  void *recv_ptr = nullptr;
+  std::vector<Triple> send;            // index: destination rank (mine stays empty)
+  std::vector<uint64_t> rows_from, nnz_from;
+  bool prepared = false;
 
   static void upload(spgemm_ctx *ctx, const matrix::CSRMatrix<> &m, spgemm_mat **out) {
     std::vector<uint64_t> ptr(m.height + 1);
@@ -226,6 +240,9 @@ public:
 
   ~HipSpgemm() override {
     if (d_col_new_id) spgemm_buffer_free(ctx, d_col_new_id);
+    for (void *p : {recv.len, recv.col, recv.val, recv_ptr}) spgemm_buffer_free(ctx, p);
+    for (auto &t : send)
+      for (void *p : {t.len, t.col, t.val}) spgemm_buffer_free(ctx, p);
     spgemm_mat_free(ctx, C);
     spgemm_mat_free(ctx, part_A);
     spgemm_mat_free(ctx, block_B);
@@ -266,67 +283,88 @@ public:
       }
   }
 
-  void gemm(std::vector<size_t> /*serialized_sizes_B_bytes*/, size_t /*max_size_B_bytes*/) override {
-    auto *ms = measure::Measure::get_instance(rank);
-    if (bitmaps.size() != (size_t)n_nodes) throw std::runtime_error("bitmaps were not shared before gemm");
-    // receive-side sizes
-    uint64_t rows_total = 0, nnz_total = 0;
-    std::vector<uint64_t> rows_from(n_nodes), nnz_from(n_nodes);
+  // Allocates the exchange buffers; call once, after `bitmaps` holds every rank's bitmap.
+  void prepare() {
+    if (prepared) return;
+    if (bitmaps.size() != (size_t)n_nodes) throw std::runtime_error("bitmaps were not shared before prepare");
+    rows_from.assign(n_nodes, 0);
+    nnz_from.assign(n_nodes, 0);
     for (int s = 0; s < n_nodes; ++s) {
       world.ops.at(s)->provided(rank, &rows_from[s], &nnz_from[s]);
-      rows_total += rows_from[s];
-      nnz_total += nnz_from[s];
+      recv.rows += rows_from[s];
+      recv.nnz += nnz_from[s];
     }
-    void *d_len = nullptr, *d_col = nullptr, *d_val = nullptr, *d_ptr = nullptr;
-    HOST_TRY(spgemm_buffer_alloc(ctx, rows_total * 4 + 4, &d_len));
-    HOST_TRY(spgemm_buffer_alloc(ctx, nnz_total * 4 + 4, &d_col));
-    HOST_TRY(spgemm_buffer_alloc(ctx, nnz_total * 8 + 8, &d_val));
-    HOST_TRY(spgemm_buffer_alloc(ctx, (b_rows_total + 1) * 8, &d_ptr));
-    // pull the marked sections of every rank, ascending (the order of the rows of B)
+    HOST_TRY(spgemm_buffer_alloc(ctx, recv.rows * 4 + 4, &recv.len));
+    HOST_TRY(spgemm_buffer_alloc(ctx, recv.nnz * 4 + 4, &recv.col));
+    HOST_TRY(spgemm_buffer_alloc(ctx, recv.nnz * 8 + 8, &recv.val));
+    HOST_TRY(spgemm_buffer_alloc(ctx, (b_rows_total + 1) * 8, &recv_ptr));
+    send.assign(n_nodes, Triple());
+    for (int d = 0; d < n_nodes; ++d) {
+      if (d == rank) continue;
+      provided(d, &send[d].rows, &send[d].nnz);
+      if (!send[d].rows) continue;
+      HOST_TRY(spgemm_buffer_alloc(ctx, send[d].rows * 4 + 4, &send[d].len));
+      HOST_TRY(spgemm_buffer_alloc(ctx, send[d].nnz * 4 + 4, &send[d].col));
+      HOST_TRY(spgemm_buffer_alloc(ctx, send[d].nnz * 8 + 8, &send[d].val));
+    }
+    prepared = true;
+  }
+
+  // Called by every rank's thread at the same time (the ranks meet in world.barrier()):
+  //  1. filter: my sections that each destination's bitmap marks are packed into my send buffer for
+  //     it (BlockedCSRMatrix::filter, reference include/matrix_impl.hpp:507-534); my own go straight
+  //     into my receive buffer;
+  //  2. barrier: every rank's send buffers are complete;
+  //  3. the sections I need are copied from the owners' send buffers, ascending (peer to peer between
+  //     GPUs), the row pointer of the local full-height B is rebuilt, one multiply follows.
+  // The send buffers are written again only in the next gemm, which starts behind the driver's
+  // barrier, i.e. after every rank has finished this one.
+  void gemm(std::vector<size_t> /*serialized_sizes_B_bytes*/, size_t /*max_size_B_bytes*/) override {
+    auto *ms = measure::Measure::get_instance(rank);
+    prepare();
+    measure_point(rank, measure::filter, measure::MeasurementEvent::START);
+    uint64_t my_ro = 0, my_zo = 0; // where my own sections go in the receive buffer
+    for (int s = 0; s < rank; ++s) { my_ro += rows_from[s]; my_zo += nnz_from[s]; }
+    for (int d = 0; d < n_nodes; ++d) {
+      auto words = bitmap::to_words(bitmaps[d]);
+      uint64_t r = 0, z = 0;
+      if (d == rank) {
+        if (!rows_from[rank]) continue;
+        HOST_TRY(spgemm_pack_sections(ctx, block_B, opt.n_sections, b_first_row, b_rows_total, words.data(),
+                                      (uint32_t *)recv.len + my_ro, (uint32_t *)recv.col + my_zo, (double *)recv.val + my_zo,
+                                      &r, &z));
+        if (r != rows_from[rank] || z != nnz_from[rank]) throw std::runtime_error("section exchange: size mismatch");
+      } else if (send[d].rows) {
+        HOST_TRY(spgemm_pack_sections(ctx, block_B, opt.n_sections, b_first_row, b_rows_total, words.data(),
+                                      (uint32_t *)send[d].len, (uint32_t *)send[d].col, (double *)send[d].val, &r, &z));
+        if (r != send[d].rows || z != send[d].nnz) throw std::runtime_error("section exchange: size mismatch");
+        ms->track_bytes(r * 4 + z * 12); // bytes this rank sends (counted at the sender, like communication::send)
+      }
+    }
+    HOST_TRY(spgemm_synchronize(ctx));
+    measure_point(rank, measure::filter, measure::MeasurementEvent::END);
     measure_point(rank, measure::wait_all, measure::MeasurementEvent::START);
-    auto words = bitmap::to_words(bitmaps[rank]);
+    world.barrier();
     uint64_t ro = 0, zo = 0;
     for (int s = 0; s < n_nodes; ++s) {
-      HipSpgemm *src = world.ops[s];
-      if (!rows_from[s]) continue;
-      uint64_t r = 0, z = 0;
-      uint32_t *len_dst = (uint32_t *)d_len + ro, *col_dst = (uint32_t *)d_col + zo;
-      double *val_dst = (double *)d_val + zo;
-      if (src->ctx == ctx || same_device(src->ctx, ctx)) {
-        HOST_TRY(spgemm_pack_sections(src->ctx, src->block_B, opt.n_sections, src->b_first_row, b_rows_total, words.data(),
-                                      len_dst, col_dst, val_dst, &r, &z));
-      } else {
-        void *t_len = nullptr, *t_col = nullptr, *t_val = nullptr;
-        HOST_TRY(spgemm_buffer_alloc(src->ctx, rows_from[s] * 4 + 4, &t_len));
-        HOST_TRY(spgemm_buffer_alloc(src->ctx, nnz_from[s] * 4 + 4, &t_col));
-        HOST_TRY(spgemm_buffer_alloc(src->ctx, nnz_from[s] * 8 + 8, &t_val));
-        HOST_TRY(spgemm_pack_sections(src->ctx, src->block_B, opt.n_sections, src->b_first_row, b_rows_total, words.data(),
-                                      (uint32_t *)t_len, (uint32_t *)t_col, (double *)t_val, &r, &z));
-        HOST_TRY(spgemm_buffer_copy(ctx, len_dst, src->ctx, t_len, r * 4));
-        HOST_TRY(spgemm_buffer_copy(ctx, col_dst, src->ctx, t_col, z * 4));
-        HOST_TRY(spgemm_buffer_copy(ctx, val_dst, src->ctx, t_val, z * 8));
-        HOST_TRY(spgemm_synchronize(ctx));
-        spgemm_buffer_free(src->ctx, t_len); spgemm_buffer_free(src->ctx, t_col); spgemm_buffer_free(src->ctx, t_val);
+      if (s != rank && rows_from[s]) {
+        const Triple &t = world.ops[s]->send[rank];
+        if (t.rows != rows_from[s] || t.nnz != nnz_from[s]) throw std::runtime_error("section exchange: size mismatch");
+        HOST_TRY(spgemm_buffer_copy(ctx, (uint32_t *)recv.len + ro, world.ops[s]->ctx, t.len, t.rows * 4));
+        HOST_TRY(spgemm_buffer_copy(ctx, (uint32_t *)recv.col + zo, world.ops[s]->ctx, t.col, t.nnz * 4));
+        HOST_TRY(spgemm_buffer_copy(ctx, (double *)recv.val + zo, world.ops[s]->ctx, t.val, t.nnz * 8));
       }
-      if (r != rows_from[s] || z != nnz_from[s]) throw std::runtime_error("section exchange: size mismatch");
-      ro += r;
-      zo += z;
+      ro += rows_from[s];
+      zo += nnz_from[s];
     }
     measure_point(rank, measure::wait_all, measure::MeasurementEvent::END);
-    // bytes this rank sends per gemm (counted at the sender, like communication::send)
-    for (int d = 0; d < n_nodes; ++d)
-      if (d != rank) {
-        uint64_t r, z;
-        provided(d, &r, &z);
-        ms->track_bytes(r * 4 + z * 12);
-      }
     measure_point(rank, measure::deserialize, measure::MeasurementEvent::START);
-    uint64_t nnz_b = 0;
-    HOST_TRY(spgemm_assemble_row_ptr(ctx, b_rows_total, opt.n_sections, words.data(), (const uint32_t *)d_len, rows_total,
-                                     (uint64_t *)d_ptr, &nnz_b));
+    auto words = bitmap::to_words(bitmaps[rank]);
+    HOST_TRY(spgemm_assemble_row_ptr(ctx, b_rows_total, opt.n_sections, words.data(), (const uint32_t *)recv.len, recv.rows,
+                                     (uint64_t *)recv_ptr, nullptr));
     spgemm_mat *B_local = nullptr;
-    HOST_TRY(spgemm_mat_wrap_device(ctx, b_rows_total, b_cols, nnz_b, (const uint64_t *)d_ptr, (const uint32_t *)d_col,
-                                    (const double *)d_val, 0, &B_local));
+    HOST_TRY(spgemm_mat_wrap_device(ctx, b_rows_total, b_cols, recv.nnz, (const uint64_t *)recv_ptr, (const uint32_t *)recv.col,
+                                    (const double *)recv.val, 0, &B_local));
     measure_point(rank, measure::deserialize, measure::MeasurementEvent::END);
     measure_point(rank, measure::mult, measure::MeasurementEvent::START);
     HOST_TRY(spgemm_multiply(ctx, part_A, B_local, &C));
@@ -344,8 +382,6 @@ public:
     ms->add_interval_ns(measure::symbolic, st.ms_symbolic * 1e6);
     ms->add_interval_ns(measure::numeric, st.ms_numeric * 1e6);
     spgemm_mat_free(ctx, B_local);
-    spgemm_buffer_free(ctx, d_len); spgemm_buffer_free(ctx, d_col); spgemm_buffer_free(ctx, d_val);
-    spgemm_buffer_free(ctx, d_ptr);
   }
 
   spgemm_stats last_stats{};

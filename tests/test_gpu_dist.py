@@ -72,6 +72,7 @@ def test_section_helpers_match_numpy():
     t_val = torch.empty(nnz_want, dtype=torch.float64, device="cuda")
     r, z = ctx.pack_sections(d, N, first, total, bits, t_len.data_ptr(), t_col.data_ptr(), t_val.data_ptr())
     assert (r, z) == (rows_want, nnz_want)
+    ctx.synchronize()  # pack_sections only queues its copies on the context's stream
     keep_rows = np.concatenate([np.arange(lo[s], hi[s]) for s in np.flatnonzero(bits)])
     sel = sd.select_rows(blk, keep_rows)
     assert np.array_equal(t_len.cpu().numpy(), np.diff(sel.row_ptr.astype(np.int64)))
