@@ -101,6 +101,19 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   big_win_words                                   bitmap window of the big-row symbolic kernel
  *                                                   (32-column words, multiple of 1024, <= 32768)
  *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)
+ *   slice_queues                                    1..8 work queues of that kernel (workgroup b starts
+ *                                                   on queue b mod queues: 8 = one queue per XCD)
+ *   slice_run_min, slice_run_div                    chunks per work item of that kernel: at least
+ *                                                   run_min (4..64), one more per run_div A entries
+ *   slice_sorted                                    1: its work items are taken in the order of their
+ *                                                   first output column instead of row by row
+ *   slice_packed                                    1: it reads B as 16-byte {column, value} records
+ *                                                   (built once per B handle)
+ *   lane_order_adds                                 1 (default): where the device passed the probe run
+ *                                                   by spgemm_create (one LDS fp64 add applies lanes
+ *                                                   that share an address in lane order), the flat
+ *                                                   walks add 64 products with one instruction;
+ *                                                   0: always resolve such lanes in claim rounds
  *   hash_num_slice                                  LDS-hash rows with more outputs than this are
  *                                                   accumulated by the big-row numeric kernel
  *   global_blocks_sym, global_blocks_num            workgroups of the unsorted-B fallback kernels

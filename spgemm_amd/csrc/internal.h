@@ -14,4 +14,8 @@ int spgemm_internal_alloc_mat(spgemm_ctx *ctx, uint64_t rows, uint64_t cols, uin
 // a block from the context's buffer pool / back to it (the stream must have drained the block's users)
 int spgemm_internal_pool_alloc(spgemm_ctx *ctx, size_t bytes, void **p, size_t *got);
 void spgemm_internal_pool_release(spgemm_ctx *ctx, void *p, size_t got);
+// sorts n pairs of (32-bit key, 12-byte record) by key on `stream`.  tmp == nullptr: only *tmp_bytes
+// (the scratch the sort needs) is set.
+int spgemm_internal_sort_records12(hipStream_t stream, const uint32_t *key_in, uint32_t *key_out, const void *rec_in,
+                                   void *rec_out, size_t n, void *tmp, size_t *tmp_bytes);
 }

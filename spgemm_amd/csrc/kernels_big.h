@@ -29,7 +29,15 @@ __host__ __device__ inline size_t sym_big_lds(uint32_t win_words) {
 
 __global__ void __launch_bounds__(BIG_THREADS)
     k_sym_big(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t win_words,
-              uint64_t *__restrict__ g_state, uint64_t nnz_a) {
+              uint64_t *__restrict__ g_state, uint64_t nnz_a, unsigned long long *__restrict__ stamps) {
+#ifdef SG_SYM_STAMPS
+  // diagnostic build: cycles per phase, summed over the wavefronts into stamps[0..7]
+  unsigned long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define SY_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define SY_STAMP(i)
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
   uint64_t *s_pos = reinterpret_cast<uint64_t *>(smem + (size_t)win_words * 4);
@@ -84,7 +92,9 @@ __global__ void __launch_bounds__(BIG_THREADS)
           s_mid[atomicAdd(&s_n[0], 1u)] = idx;
         }
       }
+      SY_STAMP(0)
       __syncthreads();
+      SY_STAMP(1)
       const uint32_t nmid = s_n[0], nlong = s_n[1];
       // mid pieces: a wavefront takes four pieces and all of their (up to 4 x 64) entries at once
       for (uint32_t e0 = wv * 4u; e0 < nmid; e0 += BIG_WAVES * 4u) {
@@ -114,6 +124,7 @@ __global__ void __launch_bounds__(BIG_THREADS)
           if (lane == 0 && rem[u]) pos[id[u]] = p[u] + took;
         }
       }
+      SY_STAMP(2)
       // long pieces: all wavefronts, 1024 entries of a piece per step, four pieces at a time
       for (uint32_t e0 = 0; e0 < nlong; e0 += 4u) {
         uint32_t c[4];
@@ -125,8 +136,17 @@ __global__ void __launch_bounds__(BIG_THREADS)
           p[u] = pos[id];
           rem[u] = on ? end[id] - p[u] : 0ull;
         }
+#ifdef SG_SYM_STAMPS
+        if (p[0] + rem[1] + p[2] + rem[3] == 0x123456789ull) carry++; // the loads of p and rem have to land
+        { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[8] += tn - tlast; tlast = tn; }
+        tph[10] += 1;
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) c[u] = tid < rem[u] ? B.col[p[u] + tid] : EMPTY_KEY;
+#ifdef SG_SYM_STAMPS
+        if (c[0] + c[1] + c[2] + c[3] == 0x12345678u) carry++; // the loads have to land
+        { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[9] += tn - tlast; tlast = tn; }
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const bool in = tid < rem[u] && (last || (uint64_t)c[u] < chi);
@@ -141,11 +161,16 @@ __global__ void __launch_bounds__(BIG_THREADS)
             if (in2) atomicOr(&bits[(c2 >> 5) - wb], 1u << (c2 & 31u));
             n = (uint32_t)__popcll(__ballot(in2));
             took += n;
+#ifdef SG_SYM_STAMPS
+            tph[11] += 1;
+#endif
           }
           if (lane == 0 && took) atomicAdd(&s_cnt[e0 + u], took);
         }
       }
+      SY_STAMP(3)
       __syncthreads();
+      SY_STAMP(4)
       if (tid < nlong) pos[s_long[tid]] += s_cnt[tid];
       if (tid < 2) s_n[tid] = 0u;
       if (kb + BIG_CUR < len_a) __syncthreads(); // the lists are filled again by the next batch
@@ -172,6 +197,7 @@ __global__ void __launch_bounds__(BIG_THREADS)
         if (lane == 63) s_blk[b] = incl;
       }
     }
+    SY_STAMP(5)
     __syncthreads();
     // every wavefront scans the block totals for itself (nblk <= 128: two per lane)
     const uint32_t t0 = 2u * lane < nblk ? s_blk[2u * lane] : 0u;
@@ -199,8 +225,14 @@ __global__ void __launch_bounds__(BIG_THREADS)
       }
     }
     carry += tot;
+    SY_STAMP(6)
     __syncthreads(); // s_blk and the lists are reused by the next window
+    SY_STAMP(7)
   }
+#ifdef SG_SYM_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&stamps[i], tph[i]);
+#endif
   if (tid == 0) {
     m.nnz[row] = carry;
     m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry, m.hash_num_max);
@@ -223,41 +255,59 @@ __global__ void __launch_bounds__(BIG_THREADS)
 #ifndef SG_SLICE_UG
 #define SG_SLICE_UG 4
 #endif
-constexpr uint32_t SLICE_W = 1024;
-constexpr uint32_t SLICE_LDS = SLICE_W * 16u + FLAT_BYTES; // cols u32 | vals f64 | owner u32 | flat-walk scratch
+#ifndef SG_SLICE_W
+#define SG_SLICE_W 1024
+#endif
+constexpr uint32_t SLICE_W = SG_SLICE_W; // 4^k, 2 * 4^k or 3 * 4^k, a multiple of 64
+// largest power of four that divides SLICE_W into at most three parts: the position search splits
+// into those parts first and four ways from there on
+constexpr uint32_t SLICE_P4 = SLICE_W % 1024u == 0 && SLICE_W / 1024u <= 3u ? 1024u : SLICE_W % 256u == 0 && SLICE_W / 256u <= 3u ? 256u : 64u;
+static_assert(SLICE_W % 64u == 0 && SLICE_W % SLICE_P4 == 0 && SLICE_W / SLICE_P4 <= 3u, "unsupported SLICE_W");
+// LDS of one workgroup: cols u32 | vals f64 | owner u32 (claim rounds only) | flat-walk scratch
+__host__ __device__ constexpr uint32_t slice_lds(bool hw_order) { return SLICE_W * (hw_order ? 12u : 16u) + FLAT_BYTES; }
+#ifndef SG_SLICE_PF
+#define SG_SLICE_PF 3
+#endif
+constexpr int SLICE_PF = SG_SLICE_PF; // steps of 64 products whose loads fly ahead of the step that is added
 
 struct SliceItem {
   uint32_t row, c0, nc; // chunks [c0, c0 + nc) of the row
 };
 
 // chunks per item: long A rows get longer runs, so that building the list pays off
-__host__ __device__ inline uint32_t slice_run(uint32_t len_a) {
-  uint32_t g = len_a / 64u;
-  return g < 4u ? 4u : g > 64u ? 64u : g;
+// run_min >= 4; run_div: entries of the A row per chunk of a run
+__host__ __device__ inline uint32_t slice_run(uint32_t len_a, uint32_t run_min, uint32_t run_div) {
+  uint32_t g = len_a / run_div;
+  return g < run_min ? run_min : g > 64u ? 64u : g;
 }
 
 __global__ void __launch_bounds__(256)
     k_slice_count(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
-                  const uint32_t *__restrict__ nnz, uint32_t *__restrict__ count) {
+                  const uint32_t *__restrict__ nnz, uint32_t *__restrict__ count, uint32_t run_min, uint32_t run_div) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows) return;
   const uint32_t row = rows[i];
   const uint32_t chunks = (nnz[row] + SLICE_W - 1u) / SLICE_W;
-  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]));
+  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]), run_min, run_div);
   count[i] = (chunks + g - 1u) / g;
 }
 
 __global__ void __launch_bounds__(256)
     k_slice_fill(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
                  const uint32_t *__restrict__ nnz, const uint64_t *__restrict__ offset,
-                 SliceItem *__restrict__ items) {
+                 SliceItem *__restrict__ items, uint32_t *__restrict__ keys, RowMeta m, uint32_t run_min,
+                 uint32_t run_div) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows) return;
   const uint32_t row = rows[i];
   const uint32_t chunks = (nnz[row] + SLICE_W - 1u) / SLICE_W;
-  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]));
+  const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]), run_min, run_div);
+  const uint32_t *tin = keys ? m.temp_cols + m.t_off[m.lead[row]] : nullptr;
   uint64_t o = offset[i];
-  for (uint32_t c = 0; c < chunks; c += g) items[o++] = SliceItem{row, c, min(g, chunks - c)};
+  for (uint32_t c = 0; c < chunks; c += g) {
+    if (keys) keys[o] = tin[(size_t)c * SLICE_W]; // the item's first output column: the sort key
+    items[o++] = SliceItem{row, c, min(g, chunks - c)};
+  }
 }
 
 // longest A row among the rows of the numeric phase's big-row bin (atomic max into out[0], zero on entry)
@@ -272,16 +322,18 @@ __global__ void __launch_bounds__(256)
 }
 
 // first position in [lo, hi) of B.col whose column is >= key (per lane)
+// STRIDE: distance of consecutive columns in `col`, in uint32 (4 for the packed {column, value} records)
+template <int STRIDE = 1>
 __device__ __forceinline__ uint64_t lower_bound_col(const uint32_t *__restrict__ col, uint64_t lo, uint64_t hi,
                                                     uint64_t key) {
   while (lo < hi) {
     const uint64_t mid = lo + ((hi - lo) >> 1);
-    if ((uint64_t)col[mid] < key) lo = mid + 1; else hi = mid;
+    if ((uint64_t)col[mid * STRIDE] < key) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
 // the same for N independent ranges per lane, their loads in flight together
-template <int N>
+template <int N, int STRIDE = 1>
 __device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ col, uint64_t (&lo)[N], uint64_t (&hi)[N],
                                                   uint64_t key) {
   for (;;) {
@@ -294,7 +346,7 @@ __device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ c
 #pragma unroll
     for (int u = 0; u < N; ++u) {
       mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1);
-      c[u] = lo[u] < hi[u] ? col[mid[u]] : 0u;
+      c[u] = lo[u] < hi[u] ? col[mid[u] * STRIDE] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < N; ++u)
@@ -304,20 +356,53 @@ __device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ c
   }
 }
 
-// `work`: [0] = next item to hand out (zero on entry), total = n_items[0].  o.zero_count[3] is set
+// `work`: SLICE_QUEUE_STRIDE * q = items handed out from queue q (zero on entry); queue q holds the
+// items [total * q / queues, total * (q + 1) / queues), total = n_items[0].  Workgroups are dealt to
+// the eight XCDs round robin, so workgroup b starts on queue b % queues and moves on to the next
+// one when a queue runs dry.  With eight queues the wavefronts of ONE XCD work on consecutive items,
+// that is on the chunks of a few rows of A at a time: the B rows those chunks share come from HBM
+// once and from that XCD's L2 afterwards, instead of once per XCD.  o.zero_count[3] is set
 // when a list entry read back from scratch is not a position inside B (never seen; it would mean
 // that the list was damaged) - the entry is skipped and the host reports the multiply as failed.
 // list_scratch: per workgroup, list_cap entries of {cur u64 | end u64 | av f64 | next u32 | queue u32}.
 constexpr uint32_t SLICE_ENTRY_BYTES = 32;
+constexpr uint32_t SLICE_MAX_QUEUES = 8;
+constexpr uint32_t SLICE_QUEUE_STRIDE = 16; // counters, in uint64: one 128-byte line each
 __global__ void __launch_bounds__(64)
     k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
                 NumOut o, unsigned long long *__restrict__ work, unsigned char *__restrict__ list_scratch,
-                uint64_t list_cap, uint64_t nnz_b) {
+                uint64_t list_cap, uint64_t nnz_b, const uint4 *__restrict__ packed, uint32_t queues, uint32_t hw_order) {
+  // the entries of B as 16-byte records {column, -, value}: a short piece of a row of B (a few entries,
+  // the common case inside a chunk) then lies in ONE 128-byte line instead of one line of columns and
+  // one of values, and this kernel is bound by the lines it pulls in
+  const uint32_t *__restrict__ pcol = reinterpret_cast<const uint32_t *>(packed);
+  auto bcol = [&](uint64_t i) -> uint32_t { return packed ? pcol[i * 4u] : B.col[i]; };
+  auto bpair = [&](uint64_t i, uint32_t &c, double &v) {
+    if (packed) {
+      const uint4 t = packed[i];
+      c = t.x;
+      v = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
+    } else {
+#if defined(SG_ABL_COL)  // diagnostic builds: the loads of one kind go to a cache-resident kilobyte (wrong results)
+      c = B.col[i & 1023u];
+#else
+      c = B.col[i];
+#endif
+#if defined(SG_ABL_VAL)
+      v = B.val[i & 1023u];
+#else
+      v = B.val[i];
+#endif
+    }
+  };
+  auto lbound = [&](uint64_t lo, uint64_t hi, uint64_t key) {
+    return packed ? lower_bound_col<4>(pcol, lo, hi, key) : lower_bound_col<1>(B.col, lo, hi, key);
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *scol = reinterpret_cast<uint32_t *>(smem);
   double *vals = reinterpret_cast<double *>(smem + SLICE_W * 4u);
   uint32_t *owner = reinterpret_cast<uint32_t *>(smem + SLICE_W * 12u);
-  unsigned char *flat = smem + SLICE_W * 16u;
+  unsigned char *flat = smem + SLICE_W * (hw_order ? 12u : 16u);
   uint32_t *st = reinterpret_cast<uint32_t *>(flat);
   uint64_t *p0s = reinterpret_cast<uint64_t *>(flat + 256);
   double *avs = reinterpret_cast<double *>(flat + 768);
@@ -328,24 +413,33 @@ __global__ void __launch_bounds__(64)
   uint32_t *l_next = reinterpret_cast<uint32_t *>(l_av + list_cap);
   uint32_t *l_q = l_next + list_cap;
   const uint64_t total_items = n_items[0];
-  for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
+  if (!hw_order)
+    for (uint32_t i = lane; i < SLICE_W; i += 64) owner[i] = 0u;
   uint32_t stamp = 0;
   uint32_t nz = 0;
   constexpr int U = 4;  // blocks of list entries whose loads and searches are in flight together
   constexpr int UG = SG_SLICE_UG; // B row pieces whose loads and column searches are in flight together
 #ifdef SG_SLICE_STAMPS
   // diagnostic build: cycles per phase, summed over the wavefronts into o.zero_count[8..]
-  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #define SG_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
 #else
 #define SG_STAMP(i)
 #endif
+  const uint32_t home = blockIdx.x % queues;
+  uint32_t tried = 0; // queues found dry so far
   for (;;) {
     unsigned long long t = 0;
-    if (lane == 0) t = atomicAdd(work, 1ull);
-    t = readlane64(t, 0);
-    if (t >= total_items) break;
+    while (tried < queues) { // wave-uniform
+      const uint32_t q = (home + tried) % queues;
+      const unsigned long long q_lo = total_items * q / queues, q_hi = total_items * (q + 1ull) / queues;
+      if (lane == 0) t = q_lo + atomicAdd(work + (size_t)SLICE_QUEUE_STRIDE * q, 1ull);
+      t = readlane64(t, 0);
+      if (t < q_hi) break;
+      ++tried;
+    }
+    if (tried >= queues) break;
     SG_STAMP(0)
     const SliceItem it = items[t];
     const uint32_t row = it.row;
@@ -372,9 +466,9 @@ __global__ void __launch_bounds__(64)
         av = A.val[ka];
         const uint64_t b0 = B.ptr[k];
         b1 = B.ptr[k + 1];
-        lo = item_first ? b0 : lower_bound_col(B.col, b0, b1, clo_item);
+        lo = item_first ? b0 : lbound(b0, b1, clo_item);
       }
-      nextc = lo < b1 ? B.col[lo] : EMPTY_KEY;
+      nextc = lo < b1 ? bcol(lo) : EMPTY_KEY;
       const bool ne = lo < b1 && (uint64_t)nextc < chi_item;
       cur = ne ? lo : 0;
       end = ne ? b1 : 0;
@@ -396,10 +490,11 @@ __global__ void __launch_bounds__(64)
             hi[u] = item_first ? lo[u] : b1[u]; // empty range: nothing to search
           }
         }
-        lower_bound_col_n<U>(B.col, lo, hi, clo_item);
+        if (packed) lower_bound_col_n<U, 4>(pcol, lo, hi, clo_item);
+        else lower_bound_col_n<U, 1>(B.col, lo, hi, clo_item);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t nc0 = lo[u] < b1[u] ? B.col[lo[u]] : EMPTY_KEY;
+          const uint32_t nc0 = lo[u] < b1[u] ? bcol(lo[u]) : EMPTY_KEY;
           const bool ne = lo[u] < b1[u] && (uint64_t)nc0 < chi_item;
           const uint64_t mask = __ballot(ne);
           if (ne) {
@@ -445,8 +540,14 @@ __global__ void __launch_bounds__(64)
       // flight together (five dependent LDS round trips instead of ten)
       auto find = [&](uint32_t col) {
         uint32_t pos = 0;
+        if constexpr (SLICE_W > SLICE_P4) {
+          uint32_t part = 0;
 #pragma unroll
-        for (uint32_t len = SLICE_W / 4; len > 0; len >>= 2) {
+          for (uint32_t j = 1; j < SLICE_W / SLICE_P4; ++j) part += scol[j * SLICE_P4] <= col ? 1u : 0u;
+          pos = part * SLICE_P4;
+        }
+#pragma unroll
+        for (uint32_t len = SLICE_P4 / 4; len > 0; len >>= 2) {
           const uint32_t a = scol[pos + len], b = scol[pos + 2u * len], c = scol[pos + 3u * len];
           pos += len * ((a <= col ? 1u : 0u) + (b <= col ? 1u : 0u) + (c <= col ? 1u : 0u));
         }
@@ -485,8 +586,9 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
               const bool have = lane < g.rem[u];
-              g.col[u] = have ? B.col[g.p0[u] + lane] : EMPTY_KEY;
-              g.v[u] = have ? B.val[g.p0[u] + lane] : 0.0;
+              g.col[u] = EMPTY_KEY;
+              g.v[u] = 0.0;
+              if (have) bpair(g.p0[u] + lane, g.col[u], g.v[u]);
             }
           };
           Group g, gn;
@@ -515,8 +617,9 @@ __global__ void __launch_bounds__(64)
                 while (ncur < g.pend[u]) { // the whole block belonged to the chunk and the B row goes on
                   const uint32_t r2 = (uint32_t)min(g.pend[u] - ncur, (uint64_t)64);
                   const bool have = lane < r2;
-                  const uint32_t c2 = have ? B.col[ncur + lane] : EMPTY_KEY;
-                  const double v2 = have ? B.val[ncur + lane] : 0.0;
+                  uint32_t c2 = EMPTY_KEY;
+                  double v2 = 0.0;
+                  if (have) bpair(ncur + lane, c2, v2);
                   const bool in2 = have && (uint64_t)c2 < chi;
                   if (in2) lds_add_f64(&vals[find(c2)], __dmul_rn(g.a[u], v2));
                   took = (uint32_t)__popcll(__ballot(in2));
@@ -533,6 +636,10 @@ __global__ void __launch_bounds__(64)
             g = gn;
           }
           SG_STAMP(4)
+#ifdef SG_SLICE_STAMPS
+          tph[18] += 1;    // long-piece blocks
+          tph[19] += nact; // long pieces
+#endif
         } else {
           // short pieces: products laid end to end over the lanes, conflicts resolved in lane order.
           // A piece's entries are distinct columns of this chunk: at most ncols, at most chi - nextc;
@@ -542,18 +649,30 @@ __global__ void __launch_bounds__(64)
           uint32_t c1 = EMPTY_KEY, c2 = EMPTY_KEY, c3 = EMPTY_KEY;
           if (act) {
             lim = min(end, cur + min((uint64_t)ncols, chi - nextc));
-            c1 = cur + 1 < end ? B.col[cur + 1] : EMPTY_KEY;
-            c2 = cur + 2 < end ? B.col[cur + 2] : EMPTY_KEY;
-            c3 = cur + 3 < end ? B.col[cur + 3] : EMPTY_KEY;
+            c1 = cur + 1 < end ? bcol(cur + 1) : EMPTY_KEY;
+            c2 = cur + 2 < end ? bcol(cur + 2) : EMPTY_KEY;
+            c3 = cur + 3 < end ? bcol(cur + 3) : EMPTY_KEY;
             const bool i1 = cur + 1 < lim && (uint64_t)c1 < chi;
             const bool i2 = i1 && cur + 2 < lim && (uint64_t)c2 < chi;
             const bool i3 = i2 && cur + 3 < lim && (uint64_t)c3 < chi;
             cnt = 1u + (i1 ? 1u : 0u) + (i2 ? 1u : 0u) + (i3 ? 1u : 0u);
             if (i3 && cur + 4 < lim) { slo = cur + 4; shi = lim; }
           }
+          SG_STAMP(7)
           const bool searched = slo < shi;
-          const uint64_t found = lower_bound_col(B.col, slo, shi, chi);
+          const uint64_t found = lbound(slo, shi, chi);
           if (searched) cnt = (uint32_t)(found - cur);
+          SG_STAMP(8)
+#ifdef SG_SLICE_STAMPS
+          tph[10] += 1;                                  // flat blocks
+          tph[11] += __any(searched) ? 1 : 0;            // ... with a piece longer than four
+          tph[12] += nact;                               // pieces
+          tph[13] += group_sum<64>(cnt);                 // products
+          tph[14] += in_regs ? 1 : 0;                    // blocks of rows that keep the list in registers
+          tph[15] += (uint32_t)__popcll(__ballot(cnt == 1u));
+          tph[16] += (uint32_t)__popcll(__ballot(cnt > 4u));
+          tph[17] += group_sum<64>(cnt > 4u ? cnt : 0u); // products of pieces longer than four
+#endif
           const uint32_t incl = group_incl_scan<64>(cnt);
           const uint32_t total = group_last<64>(incl);
           lds_fence();
@@ -569,25 +688,37 @@ __global__ void __launch_bounds__(64)
             for (uint32_t sft = 32; sft > 0; sft >>= 1)
               if (st[tt + sft] <= qq) tt += sft;
             const uint64_t p = p0s[tt] + (qq - st[tt]);
-            col = valid ? B.col[p] : EMPTY_KEY;
-            bv = valid ? B.val[p] : 0.0;
+            col = EMPTY_KEY;
+            bv = 0.0;
+            if (valid) bpair(p, col, bv);
           };
-          uint32_t t_c = 0, col_c = EMPTY_KEY;
-          double bv_c = 0.0;
-          if (total) fetchq(lane, t_c, col_c, bv_c);
+          uint32_t t_q[SLICE_PF], col_q[SLICE_PF];
+          double bv_q[SLICE_PF];
+#pragma unroll
+          for (int d = 0; d < SLICE_PF; ++d) {
+            t_q[d] = 0; col_q[d] = EMPTY_KEY; bv_q[d] = 0.0;
+            if (64u * d < total) fetchq(64u * d + lane, t_q[d], col_q[d], bv_q[d]);
+          }
+#ifdef SG_SLICE_STAMPS
+          if (col_q[0] == 12345u && bv_q[0] == 0.123) nz++; // the loads have to land before the stamp
+#endif
+          SG_STAMP(9)
           for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-            uint32_t t_n = 0, col_n = EMPTY_KEY;
-            double bv_n = 0.0;
-            if (q0 + 64 < total) fetchq(q0 + 64 + lane, t_n, col_n, bv_n); // flies during this step
+            const uint32_t t_c = t_q[0], col_c = col_q[0];
+            const double bv_c = bv_q[0];
+#pragma unroll
+            for (int d = 0; d + 1 < SLICE_PF; ++d) { t_q[d] = t_q[d + 1]; col_q[d] = col_q[d + 1]; bv_q[d] = bv_q[d + 1]; }
+            t_q[SLICE_PF - 1] = 0; col_q[SLICE_PF - 1] = EMPTY_KEY; bv_q[SLICE_PF - 1] = 0.0;
+            if (q0 + 64u * SLICE_PF < total) // flies during the next steps
+              fetchq(q0 + 64u * SLICE_PF + lane, t_q[SLICE_PF - 1], col_q[SLICE_PF - 1], bv_q[SLICE_PF - 1]);
             const bool valid = col_c != EMPTY_KEY;
             const uint32_t pos = valid ? find(col_c) : 0u;
-            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[t_c], bv_c));
-            t_c = t_n; col_c = col_n; bv_c = bv_n;
+            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[t_c], bv_c), hw_order != 0);
           }
           cur += cnt;
           if (act) { // the next column is one of the three looked at, unless the piece was longer
             const uint32_t seen = cnt == 1u ? c1 : cnt == 2u ? c2 : c3;
-            nextc = cur >= end ? EMPTY_KEY : cnt <= 3u ? seen : B.col[cur];
+            nextc = cur >= end ? EMPTY_KEY : cnt <= 3u ? seen : bcol(cur);
           }
           SG_STAMP(5)
         }
@@ -649,7 +780,7 @@ __global__ void __launch_bounds__(64)
   }
 #ifdef SG_SLICE_STAMPS
   if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&o.zero_count[8 + i], tph[i]);
+    for (int i = 0; i < 20; ++i) atomicAdd(&o.zero_count[8 + i], tph[i]);
 #endif
   nz = group_sum<64>(nz);
   if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);

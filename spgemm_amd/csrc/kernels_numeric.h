@@ -19,7 +19,7 @@ struct NumOut {
 template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_num_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-                 uint32_t words, uint32_t cap, uint32_t wpb) {
+                 uint32_t words, uint32_t cap, uint32_t wpb, uint32_t hw_order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // one row per wavefront: scalar row state
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
   for (uint32_t i = lane; i < n; i += 64) {
     vals[i] = 0.0;
-    if constexpr (FLAT) owner[i] = 0u;
+    if constexpr (FLAT) if (!hw_order) owner[i] = 0u;
   }
   lds_fence();
   for (uint32_t p = lane; p < n; p += 64) {
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256)
                         stamp = 0;
                         lds_fence();
                       }
-                      claim_in_lane_order(vals, owner, stamp, lane, live && pos < n, pos, __dmul_rn(av, bv));
+                      claim_in_lane_order(vals, owner, stamp, lane, live && pos < n, pos, __dmul_rn(av, bv), hw_order != 0);
                     });
   } else {
     wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256)
 template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_num_hash(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-               uint32_t log2s, uint32_t wpb) {
+               uint32_t log2s, uint32_t wpb, uint32_t hw_order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = lane; i < S; i += 64) keys[i] = EMPTY_KEY;
   for (uint32_t i = lane; i < n; i += 64) {
     vals[i] = 0.0;
-    if constexpr (FLAT) owner[i] = 0u;
+    if constexpr (FLAT) if (!hw_order) owner[i] = 0u;
   }
   lds_fence();
   for (uint32_t p = lane; p < n; p += 64) {
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256)
         stamp = 0;
         lds_fence();
       }
-      claim_in_lane_order(vals, owner, stamp, lane, live, live ? (uint32_t)pos[h] : 0u, __dmul_rn(av, bv));
+      claim_in_lane_order(vals, owner, stamp, lane, live, live ? (uint32_t)pos[h] : 0u, __dmul_rn(av, bv), hw_order != 0);
     });
   } else {
     wave_row_walk<true>(A, B, row, lane, [&](uint32_t c, double bv, double av, uint32_t) {

@@ -138,6 +138,57 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- probe: order of the lanes of one LDS fp64 add that share an address -----------------------------
+// The flat walks add up to 64 products with ONE ds_add_f64 instruction and need the lanes that hit
+// the same accumulator to be applied in ascending lane order (the CPU's order of the products).
+// Each trial lets the 64 lanes of a wavefront add doubles of very different magnitude to a few
+// accumulators (1 .. 64 of them, at several strides, some lanes idle) and compares every
+// accumulator bit for bit with the sum taken lane by lane.  out[0] counts the differences.
+__global__ void __launch_bounds__(256) k_probe_lane_order(uint32_t trials, unsigned long long *__restrict__ out) {
+  __shared__ double acc[4][1024];
+  __shared__ double xs[4][64];
+  __shared__ uint32_t ps[4][64];
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  auto mix = [](uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+  };
+  unsigned long long bad = 0;
+  for (uint32_t t = 0; t < trials; ++t) {
+    const uint32_t cfg = blockIdx.x + t;
+    const uint32_t nslots = 1u + (cfg * 7u) % 64u;
+    const uint32_t stride = (cfg & 1u) ? 1u + 2u * ((cfg >> 1) % 17u) : 1u; // odd: distinct slots stay distinct mod 1024
+    const uint64_t h = mix(((uint64_t)blockIdx.x << 40) ^ ((uint64_t)w << 34) ^ ((uint64_t)t << 8) ^ lane);
+    const uint32_t slot = (uint32_t)(h % nslots);
+    double x = ldexp(1.0 + (double)((h >> 32) & 0xFFFFFu) / 1048576.0, (int)((h >> 20) % 60u) - 30);
+    if (h & (1ull << 60)) x = -x;
+    const bool active = (cfg & 2u) == 0 || (mix(h) % 3u) != 0;
+    for (uint32_t i = lane; i < 1024; i += 64) acc[w][i] = 0.0;
+    xs[w][lane] = x;
+    ps[w][lane] = active ? slot : 0xFFFFFFFFu;
+    __syncthreads();
+    if (active) lds_add_f64(&acc[w][(slot * stride) & 1023u], x);
+    __syncthreads();
+    if (lane < nslots) {
+      double up = 0.0;
+      for (int l = 0; l < 64; ++l)
+        if (ps[w][l] == lane) up += xs[w][l];
+      if (__double_as_longlong(acc[w][(lane * stride) & 1023u]) != __double_as_longlong(up)) ++bad;
+    }
+    __syncthreads();
+  }
+  if (bad) atomicAdd(out, bad);
+}
+
+// ---- B as 16-byte records {column, 0, value} (read by the big-row numeric kernel) ---------------------
+__global__ void __launch_bounds__(256)
+    k_pack_records(uint64_t nnz, const uint32_t *__restrict__ col, const double *__restrict__ val, uint4 *__restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(val[i]);
+    out[i] = make_uint4(col[i], 0u, (uint32_t)v, (uint32_t)(v >> 32));
+  }
+}
+
 // ---- streaming copy: what this GPU's HBM delivers to a plain 16-byte-per-lane copy ------------------------
 __global__ void __launch_bounds__(256)
     k_stream_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {

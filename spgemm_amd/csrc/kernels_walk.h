@@ -248,9 +248,17 @@ __device__ __forceinline__ void flat_walk(const Csr &A, const Csr &B, uint32_t r
 // its accumulator, adds, and the others try again in the next round.  stamp is wave-uniform.
 // Callers zero owner[] and the stamp again once the stamp passes CLAIM_STAMP_LIMIT: a tag is
 // stamp << 6 | lane, and a wrapped stamp could never win an atomic max again.
+//
+// hw_order (wave-uniform): the device applies the lanes of ONE ds_add_f64 instruction that share an
+// address in ascending lane order (k_probe_lane_order checked that when the context was made): the
+// whole call is then that single instruction, and owner[] and the stamp are not touched.
 constexpr uint32_t CLAIM_STAMP_LIMIT = 1u << 25;
 __device__ __forceinline__ void claim_in_lane_order(double *vals, uint32_t *owner, uint32_t &stamp, uint32_t lane,
-                                                    bool pending, uint32_t p, double prod) {
+                                                    bool pending, uint32_t p, double prod, bool hw_order) {
+  if (hw_order) {
+    if (pending) lds_add_f64(&vals[p], prod);
+    return;
+  }
   for (;;) {
     ++stamp;
     const uint32_t tag = (stamp << 6) | (63u - lane);

@@ -57,6 +57,8 @@ struct spgemm_mat {
   double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
   uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
   size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0, bytes_colcdf = 0;
+  uint4 *d_packed = nullptr;  // the entries as 16-byte records {column, 0, value}, read by the big-row numeric kernel
+  size_t bytes_packed = 0;
   // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
   std::vector<uint64_t> h_ptr;  // host copy of the row pointer
   uint32_t *d_rowlen = nullptr; // row lengths as uint32 (what travels in the exchange)
@@ -92,6 +94,13 @@ struct spgemm_ctx {
   Growable slice_buf; // big-row numeric: item counts, offsets, items, per-workgroup lists
   uint32_t big_rows = 1;         // big rows of a sorted B: LDS bitmap windows / output slices
   uint32_t slice_blocks = 0;     // workgroups of the slice kernel (0: fill the device)
+  bool hw_lane_order = false;    // this device passed k_probe_lane_order when the context was made
+  uint32_t lane_order_adds = 1;  // option: 0 = never rely on it (claim rounds instead)
+  uint32_t slice_queues = 1;     // work queues of the slice kernel (8: one per XCD; 1: one for the device)
+  uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
+  uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
+  uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
+  uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 16-byte {column, value} records
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
@@ -277,6 +286,18 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   return SPGEMM_OK;
 }
 
+// B as 16-byte {column, value} records for the big-row numeric kernel: built when that kernel first
+// needs them, kept on the handle like the row info.
+static int ensure_packed(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_packed || !B->nnz) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  TRY(pool_alloc(ctx, B->nnz * sizeof(uint4), (void **)&mb->d_packed, &mb->bytes_packed));
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(B->nnz, 256), (uint64_t)ctx->cu_count * 16);
+  hipLaunchKernelGGL(k_pack_records, dim3(blocks), dim3(256), 0, ctx->stream, B->nnz, B->d_col, B->d_val, mb->d_packed);
+  HIP_TRY(hipGetLastError());
+  return SPGEMM_OK;
+}
+
 // Column map of the short-row numeric kernel (entries of B per column range, prefix summed): built
 // when the first launch of that kernel needs it, kept on the handle like the row info.
 static int ensure_colcdf(spgemm_ctx *ctx, const spgemm_mat *B) {
@@ -392,6 +413,23 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       ctx->cu_count = cus;
+  }
+  // does one LDS fp64 add apply lanes that share an address in lane order?  (see k_probe_lane_order)
+  {
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(ctx->d_small);
+    unsigned long long bad = 1;
+    e = hipMemsetAsync(d_bad, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_probe_lane_order, dim3(128), dim3(256), 0, ctx->stream, 32u, d_bad);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)spgemm_destroy(ctx);
+      return fail(SPGEMM_ERR_HIP, "lane order probe failed: %s", hipGetErrorString(e));
+    }
+    ctx->hw_lane_order = bad == 0;
   }
   *out = ctx;
   return SPGEMM_OK;
@@ -555,6 +593,24 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "hash_num_slice") {
     if (value < 64 || value > 4096) return fail(SPGEMM_ERR_INVALID, "hash_num_slice must be 64..4096");
     ctx->hash_num_slice = (uint32_t)value;
+  } else if (n == "lane_order_adds") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "lane_order_adds must be 0 or 1");
+    ctx->lane_order_adds = (uint32_t)value;
+  } else if (n == "slice_queues") {
+    if (value < 1 || value > (int64_t)SLICE_MAX_QUEUES) return fail(SPGEMM_ERR_INVALID, "slice_queues must be 1..8");
+    ctx->slice_queues = (uint32_t)value;
+  } else if (n == "slice_run_min") {
+    if (value < 4 || value > 64) return fail(SPGEMM_ERR_INVALID, "slice_run_min must be 4..64");
+    ctx->slice_run_min = (uint32_t)value;
+  } else if (n == "slice_run_div") {
+    if (value < 1 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_run_div must be 1..65536");
+    ctx->slice_run_div = (uint32_t)value;
+  } else if (n == "slice_sorted") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0 or 1");
+    ctx->slice_sorted = (uint32_t)value;
+  } else if (n == "slice_packed") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_packed must be 0 or 1");
+    ctx->slice_packed = (uint32_t)value;
   } else if (n == "slice_blocks") {
     if (value < 0 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_blocks must be 0..65536");
     ctx->slice_blocks = (uint32_t)value;
@@ -730,9 +786,11 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a queued multiply may still read the row info
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
     if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+    if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
     m->d_rowinfo = nullptr;
     m->d_colcdf = nullptr;
-    m->bytes_rowinfo = m->bytes_colcdf = 0;
+    m->d_packed = nullptr;
+    m->bytes_rowinfo = m->bytes_colcdf = m->bytes_packed = 0;
   }
   return SPGEMM_OK;
 }
@@ -746,6 +804,7 @@ extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
     (void)hipStreamSynchronize(ctx->stream);
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
     if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+    if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
   }
   if (m->d_rowlen) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -876,7 +935,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint64_t *partial = ar.take<uint64_t>((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2);
   uint64_t *bin_off = ar.take<uint64_t>(MAX_BINS + 1);
   uint64_t *total_nprod = ar.take<uint64_t>(NPROD_SLOTS);
-  unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32));
+  unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE));
   uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
   uint64_t *a_p0 = short_aux ? ar.take<uint64_t>(A->nnz) : nullptr;
   uint32_t *a_len = short_aux ? ar.take<uint32_t>(A->nnz) : nullptr;
@@ -979,8 +1038,22 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 16));
       st.rows_global += cnt;
       TRY(prof_begin(ctx, 0, 4, BIG_THREADS, cnt, win_words, 0, lds, rows_bin));
+      unsigned long long *sym_stamps = reinterpret_cast<unsigned long long *>(ctx->d_small) + 32; // diagnostic builds only
+#ifdef SG_SYM_STAMPS
+      HIP_TRY(hipMemsetAsync(sym_stamps, 0, 128, ctx->stream));
+#endif
       hipLaunchKernelGGL(k_sym_big, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, win_words,
-                         reinterpret_cast<uint64_t *>(ctx->big_cur.p), A->nnz);
+                         reinterpret_cast<uint64_t *>(ctx->big_cur.p), A->nnz, sym_stamps);
+#ifdef SG_SYM_STAMPS
+      {
+        unsigned long long ph[16];
+        HIP_TRY(hipMemcpy(ph, sym_stamps, sizeof(ph), hipMemcpyDeviceToHost));
+        fprintf(stderr, "  long: position loads %.1f first step loads %.1f (rest: adds and continuation, in long below); groups of four %llu, continuation steps %llu (per wave)\n",
+                ph[8] / 1e6, ph[9] / 1e6, ph[10], ph[11]);
+        fprintf(stderr, "sym_big stamps (Mcycles, all waves): classify %.1f barrier %.1f mid %.1f long %.1f barrier %.1f popcount %.1f barrier+scan+write %.1f barrier %.1f\n",
+                ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6);
+      }
+#endif
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
@@ -1031,8 +1104,8 @@ static int numeric_prepare(spgemm_ctx *ctx, const spgemm_mat *A, const uint64_t 
   HIP_TRY(hipMemcpyAsync(&hc->total_a, d_row_ptr + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
   PartScratch ps{pl.pblocks, pl.blk_hist, pl.blk_off, pl.partial};
   TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, pl.perm, pl.bin_off));
-  HIP_TRY(hipMemsetAsync(pl.zero_count, 0, 256, ctx->stream));
-  // zero_count[1]: work counter of the slice kernel; zero_count[2] (low word): longest big A row
+  HIP_TRY(hipMemsetAsync(pl.zero_count, 0, (32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE) * 8, ctx->stream));
+  // zero_count[2] (low word): longest big A row; zero_count[32 ...]: work counters of the slice kernel
   uint32_t *max_len_big = reinterpret_cast<uint32_t *>(pl.zero_count + 2);
   if (pl.b_sorted && ctx->big_rows) {
     hipLaunchKernelGGL(k_slice_maxlen, dim3(std::min<uint32_t>(div_up_u64(rows, 256), 2048)), dim3(256), 0, ctx->stream,
@@ -1081,6 +1154,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
              pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u, pl.a_p0, pl.a_len};
   NumOut no{d_row_ptr, d_col, d_val, zero_count};
+  const uint32_t hw_order = ctx->hw_lane_order && ctx->lane_order_adds ? 1u : 0u;
   const size_t lds_max = 160 * 1024;
 
   for (int key = 0; key < NUM_NBINS; ++key) {
@@ -1134,32 +1208,54 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       TRY(prof_begin(ctx, 1, window ? 0 : 1, flat ? 0 : 64, cnt, p0, p1, lds, rows_bin));
       if (window)
         hipLaunchKernelGGL(flat ? k_num_window<true> : k_num_window<false>, grid, block, lds, ctx->stream, rows_bin, cnt,
-                           cA, cB, rm, no, p0, p1, wpb);
+                           cA, cB, rm, no, p0, p1, wpb, hw_order);
       else
         hipLaunchKernelGGL(flat ? k_num_hash<true> : k_num_hash<false>, grid, block, lds, ctx->stream, rows_bin, cnt, cA,
-                           cB, rm, no, p0, wpb);
+                           cB, rm, no, p0, wpb, hw_order);
     } else if (slices) {
       // items = runs of chunks of SLICE_W outputs; at most one per chunk
       const uint64_t max_items = nnz_structural / SLICE_W + cnt;
-      uint32_t blocks = ctx->slice_blocks ? ctx->slice_blocks : (uint32_t)ctx->cu_count * (uint32_t)(lds_max / SLICE_LDS);
+      uint32_t blocks = ctx->slice_blocks ? ctx->slice_blocks : (uint32_t)ctx->cu_count * std::min<uint32_t>(16u, (uint32_t)(lds_max / slice_lds(hw_order)));
       blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(blocks, ((uint64_t)4 << 30) / (list_cap * SLICE_ENTRY_BYTES)));
       const size_t b_count = align_up((size_t)cnt * 4, 256), b_off = align_up(((size_t)cnt + 1) * 8, 256);
       const size_t b_items = align_up(max_items * sizeof(SliceItem), 256);
-      const size_t b_lists = (size_t)blocks * list_cap * SLICE_ENTRY_BYTES;
-      TRY(grow(ctx, ctx->slice_buf, b_count + b_off + b_items + b_lists));
+      const size_t b_lists = align_up((size_t)blocks * list_cap * SLICE_ENTRY_BYTES, 256);
+      // sorted items: a run has at least four chunks, so a row of n outputs has at most n / (4 SLICE_W) + 2 items
+      const size_t sort_n = ctx->slice_sorted ? (size_t)(nnz_structural / (4ull * SLICE_W)) + 2 * (size_t)cnt : 0;
+      const size_t b_keys = align_up(sort_n * 4, 256);
+      size_t b_sort_tmp = 0;
+      if (sort_n) {
+        TRY(spgemm_internal_sort_records12(ctx->stream, nullptr, nullptr, nullptr, nullptr, sort_n, nullptr, &b_sort_tmp));
+        b_sort_tmp = align_up(b_sort_tmp, 256);
+      }
+      TRY(grow(ctx, ctx->slice_buf, b_count + b_off + b_items + b_lists + (sort_n ? 2 * b_keys + b_items + b_sort_tmp : 0)));
       char *sb = reinterpret_cast<char *>(ctx->slice_buf.p);
       uint32_t *s_count = reinterpret_cast<uint32_t *>(sb);
       uint64_t *s_off = reinterpret_cast<uint64_t *>(sb + b_count);
       SliceItem *s_items = reinterpret_cast<SliceItem *>(sb + b_count + b_off);
       unsigned char *s_lists = reinterpret_cast<unsigned char *>(sb + b_count + b_off + b_items);
-      TRY(prof_begin(ctx, 1, 4, 64, cnt, SLICE_W, blocks, SLICE_LDS, rows_bin));
+      uint32_t *s_key_in = reinterpret_cast<uint32_t *>(sb + b_count + b_off + b_items + b_lists);
+      uint32_t *s_key_out = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_key_in) + b_keys);
+      SliceItem *s_items_sorted = reinterpret_cast<SliceItem *>(reinterpret_cast<char *>(s_key_out) + b_keys);
+      void *s_sort_tmp = reinterpret_cast<char *>(s_items_sorted) + b_items;
+      if (ctx->slice_packed) TRY(ensure_packed(ctx, B));
+      TRY(prof_begin(ctx, 1, 4, 64, cnt, SLICE_W, blocks, slice_lds(hw_order), rows_bin));
       hipLaunchKernelGGL(k_slice_count, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
-                         pl.r_nnz, s_count);
+                         pl.r_nnz, s_count, ctx->slice_run_min, ctx->slice_run_div);
       TRY(launch_scan(ctx, s_count, cnt, s_off, partial));
+      if (sort_n) HIP_TRY(hipMemsetAsync(s_key_in, 0xFF, sort_n * 4, ctx->stream)); // unused tail: sorts behind every item
       hipLaunchKernelGGL(k_slice_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
-                         pl.r_nnz, s_off, s_items);
-      hipLaunchKernelGGL(k_num_slice, dim3(blocks), dim3(64), SLICE_LDS, ctx->stream, s_items, s_off + cnt, cA, cB, rm, no,
-                         zero_count + 1, s_lists, list_cap, B->nnz);
+                         pl.r_nnz, s_off, s_items, sort_n ? s_key_in : nullptr, rm, ctx->slice_run_min, ctx->slice_run_div);
+      if (sort_n) {
+        // Items in the order of their first column: the wavefronts that run together then work on
+        // the same band of columns, in whatever rows, and so on the same stretch of the (hub) rows
+        // of B, which stays in the caches instead of being fetched again for every row of A.
+        TRY(spgemm_internal_sort_records12(ctx->stream, s_key_in, s_key_out, s_items, s_items_sorted, sort_n, s_sort_tmp,
+                                           &b_sort_tmp));
+      }
+      hipLaunchKernelGGL(k_num_slice, dim3(blocks), dim3(64), slice_lds(hw_order), ctx->stream,
+                         sort_n ? s_items_sorted : s_items, s_off + cnt, cA, cB, rm, no,
+                         zero_count + 32, s_lists, list_cap, B->nnz, ctx->slice_packed ? B->d_packed : nullptr, ctx->slice_queues, hw_order);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
@@ -1183,10 +1279,13 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   if (hc->total_nprod) return fail(SPGEMM_ERR_STATE, "internal: the big-row numeric kernel met a damaged work list");
 #ifdef SG_SLICE_STAMPS
   {
-    unsigned long long ph[8];
+    unsigned long long ph[20];
     HIP_TRY(hipMemcpy(ph, zero_count + 8, sizeof(ph), hipMemcpyDeviceToHost));
     fprintf(stderr, "slice stamps (Mcycles, all waves): grab %.1f list %.1f fill %.1f scan/other %.1f per-row %.1f flat %.1f write %.1f\n",
             ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6);
+    fprintf(stderr, "  flat: first columns %.1f search %.1f scan+fetch %.1f (flat above = the add loop)\n", ph[7] / 1e6, ph[8] / 1e6, ph[9] / 1e6);
+    fprintf(stderr, "  flat blocks %llu (searched %llu, in-register rows %llu) pieces %llu products %llu; pieces of one %llu, of more than four %llu with %llu products; long blocks %llu pieces %llu\n",
+            ph[10], ph[11], ph[14], ph[12], ph[13], ph[15], ph[16], ph[17], ph[18], ph[19]);
   }
 #endif
   uint64_t zeros = hc->total_a;

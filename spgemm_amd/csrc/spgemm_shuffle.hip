@@ -109,6 +109,20 @@ inline uint32_t blocks_for(uint64_t n, uint32_t per_block = 256) { return (uint3
 
 } // namespace
 
+namespace {
+struct Record12 {
+  uint32_t a, b, c;
+};
+} // namespace
+
+extern "C" int spgemm_internal_sort_records12(hipStream_t stream, const uint32_t *key_in, uint32_t *key_out,
+                                              const void *rec_in, void *rec_out, size_t n, void *tmp, size_t *tmp_bytes) {
+  hipError_t e = rocprim::radix_sort_pairs(tmp, *tmp_bytes, key_in, key_out, static_cast<const Record12 *>(rec_in),
+                                           static_cast<Record12 *>(rec_out), n, 0, 32, stream);
+  if (e != hipSuccess) return spgemm_internal_fail(SPGEMM_ERR_HIP, hipGetErrorString(e));
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_shuffle_iterative(spgemm_ctx *ctx, const spgemm_mat *C, uint32_t iterations,
                                         uint32_t *row_shuffle, uint32_t *col_shuffle, double *row_variance) {
   if (!ctx || !C || !row_shuffle || !col_shuffle) return spgemm_internal_fail(SPGEMM_ERR_INVALID, "NULL argument");

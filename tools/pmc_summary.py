@@ -12,5 +12,7 @@ best = {}
 for (k, d), v in by.items():
     if k not in best or v["_grid"] > best[k]["_grid"]:
         best[k] = v
-for k, v in sorted(best.items(), key=lambda kv: -kv[1]["_grid"])[:8]:
-    print(k, {a: b for a, b in v.items()})
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # kernel name fragments to keep
+for k, v in sorted(best.items(), key=lambda kv: -kv[1]["_grid"]):
+    if only is None or any(o in k for o in only):
+        print(k, {a: b for a, b in v.items()})
