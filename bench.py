@@ -64,8 +64,12 @@ def measured_traffic(workload, kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_traffic_{workload}.json")))
     if not files:
         return None, None
-    k = json.load(open(files[-1]))["kernels"].get(kernel)
-    return (None, None) if k is None else (k["hbm_bytes"], os.path.relpath(files[-1], ROOT))
+    kernels = json.load(open(files[-1]))["kernels"]
+    # template arguments differ between instantiations of one kernel: the largest launch counts
+    match = [v for name, v in kernels.items() if name == kernel or name.startswith(kernel + "<")]
+    if not match:
+        return None, None
+    return max(m["hbm_bytes"] for m in match), os.path.relpath(files[-1], ROOT)
 
 
 def kernel_name(launch):

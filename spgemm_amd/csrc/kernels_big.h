@@ -5,23 +5,29 @@
 
 namespace sg {
 
-// ---- symbolic, big rows: one 1024-thread workgroup per row, bitmap windows in LDS ----------------
+// ---- symbolic, big rows: one workgroup of BIG_THREADS per row, bitmap windows in LDS --------------
 // Needs B rows with strictly increasing columns.  The row's column hull is cut into windows of
 // win_words * 32 columns.  Every A entry keeps {position, end} of what is left of its B row (in
 // LDS for rows of up to BIG_CUR entries, else in g_state, two uint64 per entry of A); in a window
 // the part of the B row that falls into it (a "piece": contiguous, the B row is sorted) is ORed
 // into the LDS bitmap and the position moves on.  Pieces are classified by what is left of the B
 // row: up to BIG_MID entries -> one wavefront takes the piece, four pieces at a time, all their
-// loads in flight together; more -> all 16 wavefronts take 1024 entries of the piece per step,
+// loads in flight together; more -> all wavefronts take BIG_THREADS entries of the piece per step,
 // four pieces at a time, and a wavefront stops at its first block that leaves the window.
 // The bitmap is then written out in blocks of 256 words (four per lane, the blocks dealt to the
 // wavefronts round robin): block totals, a scan over the blocks, and every lane writes the
 // columns of its own four words, at most 128.
 // LDS: win_words u32 bitmap | BIG_CUR u64 pos | BIG_CUR u64 end | BIG_CUR u32 list of mid pieces |
 //      BIG_CUR u32 list of long pieces | BIG_CUR u32 entries taken from long pieces | win_words / 64 u32 (block offsets; a quarter used).
-constexpr uint32_t BIG_THREADS = 1024, BIG_WAVES = 16, BIG_CUR = 1024, BIG_MID = 256;
+// 512 threads and windows of up to 16384 words: two workgroups fit the 160 KiB of a CU, and one works
+// while the other waits at a barrier (1024 threads with twice the window: 10 % slower on R-MAT 22;
+// 256 threads with half of it: 15 % slower, the rows are passed over once per window).
+#ifndef SG_BIG_THREADS
+#define SG_BIG_THREADS 512
+#endif
+constexpr uint32_t BIG_THREADS = SG_BIG_THREADS, BIG_WAVES = BIG_THREADS / 64, BIG_CUR = BIG_THREADS, BIG_MID = 256;
 static_assert(BIG_CUR == BIG_THREADS, "a batch of A entries is one entry per thread, and the piece lists hold one batch");
-constexpr uint32_t BIG_WIN_MAX = 32768;                   // words of the largest window
+constexpr uint32_t BIG_WIN_MAX = 32 * BIG_THREADS;        // words of the largest window
 constexpr uint32_t BIG_BPW = BIG_WIN_MAX / 256 / BIG_WAVES; // blocks of 256 words per wavefront and window
 __host__ __device__ inline size_t sym_big_lds(uint32_t win_words) {
   return (size_t)win_words * 4 + (size_t)BIG_CUR * (8 + 8 + 4 + 4 + 4) + (size_t)(win_words / 64) * 4;

@@ -587,7 +587,7 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "big_rows") {
     ctx->big_rows = value != 0;
   } else if (n == "big_win_words") {
-    if (value < (int64_t)BIG_THREADS || value > 32768 || value % BIG_THREADS)
+    if (value < 1024 || value > 32768 || value % 1024) // the kernel's own limit (BIG_WIN_MAX) caps it at launch
       return fail(SPGEMM_ERR_INVALID, "big_win_words must be a multiple of 1024 in 1024..32768");
     ctx->big_win_words = (uint32_t)value;
   } else if (n == "hash_num_slice") {
@@ -1033,7 +1033,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
     } else if (b_sorted && ctx->big_rows) {
       // windows of up to 2^20 columns (128 KiB of LDS); a narrower matrix gets one window
-      uint32_t win_words = (uint32_t)std::min<uint64_t>(ctx->big_win_words, align_up((B->cols + 31) / 32, BIG_THREADS));
+      uint32_t win_words = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(ctx->big_win_words, BIG_WIN_MAX), align_up((B->cols + 31) / 32, BIG_THREADS));
       size_t lds = sym_big_lds(win_words);
       if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 16));
       st.rows_global += cnt;

@@ -1,2 +1,5 @@
 set -o pipefail
-SPGEMM_AMD_LIB=$PWD/build_var/libsymst.so timeout -k 10 300 python bench.py --workload rmat --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/b_st.json 2> gpurun_out/b_st.err; grep -A1 "long:" gpurun_out/b_st.err | tail -2
+for t in 256 512; do
+SPGEMM_AMD_LIB=$PWD/build_var/libt$t.so bash tools/run2.sh | grep symbolic
+SPGEMM_AMD_LIB=$PWD/build_var/libt$t.so timeout -k 10 300 python -u -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py -m gpu -x -q --timeout 200 --timeout-method thread 2>&1 | tail -2
+done
