@@ -95,6 +95,10 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   short-row kernels (count-only symbolic pass, numeric
  *                                                   pass that sorts the row's products itself); 0: none
  *   short_rpw                                       rows one wavefront of those kernels pipelines
+ *   short_packed                                    1 (default): the numeric one reads the rows of B
+ *                                                   as 16-byte {column, value} records padded to
+ *                                                   128-byte lines (built once per B handle, at most
+ *                                                   7 records of padding per row); 0: from B's arrays
  *   g_thresh0, g_thresh1, g_thresh2                 mean B-row length classes; <= g_thresh2: flat walk
  *   flat_walk, row_groups, big_rows                 0/1 switches of the flat walk, of the grouping of
  *                                                   identical A rows, of the big-row kernels (B sorted)

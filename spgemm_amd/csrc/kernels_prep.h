@@ -38,6 +38,44 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
   }
 }
 
+// ---- B rows as padded 16-byte records, for the short-row numeric kernel ------------------------------
+// A row of up to PREC_MAX_LEN entries gets ceil(len / 8) * 8 records {column, 0, value}, starting
+// at a multiple of 128 bytes: such a row is fetched as len / 8 whole 128-byte lines, where its
+// 4-byte columns and 8-byte values in two arrays straddle three to four.  Longer rows get none (a
+// short row of A, at most 512 products, cannot refer to them).  The record start of every row goes
+// into the second half of its row-info record.
+constexpr uint32_t PREC_MAX_LEN = 512;
+__global__ void __launch_bounds__(256) k_prec_count(uint64_t rows, const uint4 *__restrict__ info, uint32_t *__restrict__ count) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const uint32_t len = info[2 * r].z;
+  count[r] = len <= PREC_MAX_LEN ? (len + 7u) & ~7u : 0u;
+}
+__global__ void __launch_bounds__(256) k_prec_patch(uint64_t rows, const uint64_t *__restrict__ start, uint4 *__restrict__ info) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  uint4 v = info[2 * r + 1];
+  v.z = (uint32_t)start[r];
+  v.w = (uint32_t)(start[r] >> 32);
+  info[2 * r + 1] = v;
+}
+__global__ void __launch_bounds__(256) k_prec_fill(uint64_t rows, const uint64_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col,
+                                                   const double *__restrict__ b_val, const uint4 *__restrict__ info,
+                                                   uint4 *__restrict__ prec) {
+  constexpr int G = 8;
+  const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const uint32_t lg = threadIdx.x & (G - 1);
+  if (row >= rows) return;
+  const uint64_t b0 = b_ptr[row], b1 = b_ptr[row + 1];
+  if (b1 - b0 > PREC_MAX_LEN) return;
+  const uint4 hi = info[2 * row + 1];
+  uint4 *out = prec + (((uint64_t)hi.w << 32) | hi.z);
+  for (uint64_t j = b0 + lg; j < b1; j += G) {
+    const unsigned long long v = (unsigned long long)__double_as_longlong(b_val[j]);
+    out[j - b0] = make_uint4(b_col[j], 0u, (uint32_t)v, (uint32_t)(v >> 32));
+  }
+}
+
 // ---- A row analysis --------------------------------------------------------------------------
 // Per A row: nprod = sum of B row lengths, [cmin, cmax] = hull of the B rows' column ranges,
 // the symbolic bin key and the upper bound `ub` on the row's distinct columns.
@@ -54,6 +92,7 @@ struct AnalyzeOut {
   uint8_t *r_same;         // 1 when the row's column list equals the previous row's (same order)
   uint64_t *a_p0;          // per A entry of a short row (kernels_short.h): start of its B row ...
   uint32_t *a_len;         // ... and the B row's length (both may be null: no short rows)
+  uint64_t *a_pk;          // ... and the start of the B row's padded records (may be null)
 };
 
 __device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32_t mn, uint32_t mx,
@@ -125,6 +164,7 @@ __global__ void __launch_bounds__(256)
         const uint4 lo = b_info[2 * k], hi = b_info[2 * k + 1];
         o.a_p0[ka] = ((uint64_t)hi.y << 32) | hi.x;
         o.a_len[ka] = lo.z;
+        if (o.a_pk) o.a_pk[ka] = ((uint64_t)hi.w << 32) | hi.z;
       }
   }
   uint64_t contrib = 0;

@@ -21,6 +21,7 @@ struct ColMap {
   const double *__restrict__ cdf; // CDF_BINS + 1 entries
   uint32_t shift;                 // bin of column c = c >> shift
   double inv_width;               // 2^-shift
+  const uint4 *__restrict__ prec; // B rows as padded {column, 0, value} records (k_prec_fill), or null
 };
 __device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
   const uint32_t b = c >> cm.shift;
@@ -68,7 +69,8 @@ __device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const Ro
   f.p0 = 0;
   f.av = 0.0;
   if (ka < a1) { // start and length of the B row: left per A entry by the analysis, read in a stream
-    f.p0 = m.a_p0[ka];
+    if constexpr (NUMERIC) f.p0 = m.a_pk ? m.a_pk[ka] : m.a_p0[ka]; // wave-uniform choice
+    else f.p0 = m.a_p0[ka];
     f.len = m.a_len[ka];
     if constexpr (NUMERIC) f.av = A.val[ka];
   }
@@ -128,10 +130,21 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
       carry = (uint32_t)__builtin_amdgcn_readlane((int)tt, 63);
       const uint32_t t = tt - 1u;
       const uint64_t p = p0s[t] + (q - st[t]);
-      if (valid) s.c[u] = B.col[p];
       s.t[u] = t;
-      if constexpr (NUMERIC)
-        if (valid) s.bv[u] = B.val[p];
+      if constexpr (NUMERIC) {
+        if (cm.prec) { // the B rows as padded records: one 16-byte load, len / 8 lines per row
+          if (valid) {
+            const uint4 rec = cm.prec[p];
+            s.c[u] = rec.x;
+            s.bv[u] = __longlong_as_double((long long)(((unsigned long long)rec.w << 32) | rec.z));
+          }
+        } else if (valid) {
+          s.c[u] = B.col[p];
+          s.bv[u] = B.val[p];
+        }
+      } else {
+        if (valid) s.c[u] = B.col[p];
+      }
     }
   }
 }

@@ -25,6 +25,7 @@ struct RowMeta {
   uint32_t hash_num_max;              // see num_key_of
   const uint64_t *__restrict__ a_p0;  // short rows: per A entry, start of its B row ...
   const uint32_t *__restrict__ a_len; // ... and the B row's length (written by the analysis)
+  const uint64_t *__restrict__ a_pk;  // ... and the start of its padded {column, value} records (may be null)
 };
 
 // ---- walking the products of one row ----------------------------------------------------------

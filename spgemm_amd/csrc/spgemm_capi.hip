@@ -57,6 +57,10 @@ struct spgemm_mat {
   double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
   uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
   size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0, bytes_colcdf = 0;
+  uint64_t *d_prow = nullptr; // scratch of the padded-record layout (row starts, scan partials, counts)
+  size_t bytes_prow = 0;
+  uint4 *d_prec = nullptr;    // rows of up to PREC_MAX_LEN entries as padded 16-byte records (short-row numeric kernel)
+  size_t bytes_prec = 0;
   uint4 *d_packed = nullptr;  // the entries as 16-byte records {column, 0, value}, read by the big-row numeric kernel
   size_t bytes_packed = 0;
   // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
@@ -97,6 +101,7 @@ struct spgemm_ctx {
   bool hw_lane_order = false;    // this device passed k_probe_lane_order when the context was made
   uint32_t lane_order_adds = 1;  // option: 0 = never rely on it (claim rounds instead)
   uint32_t slice_queues = 1;     // work queues of the slice kernel (8: one per XCD; 1: one for the device)
+  uint32_t short_packed = 1;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
   uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
@@ -132,6 +137,7 @@ struct spgemm_ctx {
     uint32_t *r_lead = nullptr;
     uint64_t *a_p0 = nullptr;  // short rows: B row start / length per A entry
     uint32_t *a_len = nullptr;
+    uint64_t *a_pk = nullptr;  // short rows: start of the B row's padded records per A entry
     uint64_t *t_off = nullptr;
     uint32_t *perm = nullptr;
     uint32_t *blk_hist = nullptr;
@@ -282,7 +288,29 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                        mb->d_rowinfo);
     HIP_TRY(hipGetLastError());
+    // where the padded records of every row would start (the records themselves: ensure_prec)
+    const size_t b_start = align_up((B->rows + 1) * 8, 256), b_part = align_up(((size_t)scan_parts(B->rows) + 2) * 8, 256);
+    TRY(pool_alloc(ctx, b_start + b_part + B->rows * 4, (void **)&mb->d_prow, &mb->bytes_prow));
+    uint64_t *partial = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mb->d_prow) + b_start);
+    uint32_t *count = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mb->d_prow) + b_start + b_part);
+    hipLaunchKernelGGL(k_prec_count, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, mb->d_rowinfo, count);
+    TRY(launch_scan(ctx, count, B->rows, mb->d_prow, partial));
+    hipLaunchKernelGGL(k_prec_patch, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, mb->d_prow,
+                       mb->d_rowinfo);
+    HIP_TRY(hipGetLastError());
   }
+  return SPGEMM_OK;
+}
+
+// B's rows as padded records for the short-row numeric kernel: built when that kernel first needs
+// them, kept on the handle like the row info.  At most 7 records of padding per row.
+static int ensure_prec(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_prec || !B->nnz) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  TRY(pool_alloc(ctx, (B->nnz + 7 * std::min<uint64_t>(B->rows, B->nnz)) * sizeof(uint4), (void **)&mb->d_prec, &mb->bytes_prec));
+  hipLaunchKernelGGL(k_prec_fill, dim3(div_up_u64(B->rows * 8, 256)), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
+                     B->d_val, B->d_rowinfo, mb->d_prec);
+  HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
 
@@ -599,6 +627,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "slice_queues") {
     if (value < 1 || value > (int64_t)SLICE_MAX_QUEUES) return fail(SPGEMM_ERR_INVALID, "slice_queues must be 1..8");
     ctx->slice_queues = (uint32_t)value;
+  } else if (n == "short_packed") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0 or 1");
+    ctx->short_packed = (uint32_t)value;
   } else if (n == "slice_run_min") {
     if (value < 4 || value > 64) return fail(SPGEMM_ERR_INVALID, "slice_run_min must be 4..64");
     ctx->slice_run_min = (uint32_t)value;
@@ -787,10 +818,14 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
     if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
     if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
+    if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
+    if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
     m->d_rowinfo = nullptr;
     m->d_colcdf = nullptr;
     m->d_packed = nullptr;
-    m->bytes_rowinfo = m->bytes_colcdf = m->bytes_packed = 0;
+    m->d_prow = nullptr;
+    m->d_prec = nullptr;
+    m->bytes_rowinfo = m->bytes_colcdf = m->bytes_packed = m->bytes_prow = m->bytes_prec = 0;
   }
   return SPGEMM_OK;
 }
@@ -805,6 +840,8 @@ extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
     pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
     if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
     if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
+    if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
+    if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
   }
   if (m->d_rowlen) {
     (void)hipStreamSynchronize(ctx->stream);
@@ -917,8 +954,11 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   need += align_up(hist_n * 4, 256) + align_up((hist_n + 1) * 8, 256); // partition histogram + scan
   need += align_up(((size_t)scan_parts(std::max<uint64_t>(rows, hist_n)) + 2) * 8, 256); // scan partials
   need += align_up((MAX_BINS + 1) * 8, 256) + NPROD_SLOTS * 8 + 256 + 256; // bin_off, counters
+  need += align_up((32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE) * 8, 256);  // zero count, flags, work queues of the slice kernel
   const bool short_aux = ctx->cp.short_max_nprod > 0;
+  const bool short_pk = short_aux && ctx->short_packed;
   if (short_aux) need += align_up(A->nnz * 8, 256) + align_up(A->nnz * 4, 256); // short rows: B row start and length per A entry
+  if (short_pk) need += align_up(A->nnz * 8, 256);                               // ... and the start of its padded records
   TRY(grow(ctx, ctx->arena, need));
   ArenaCursor ar{reinterpret_cast<char *>(ctx->arena.p), 0, ctx->arena.cap};
   uint32_t *r_cmin = ar.take<uint32_t>(rows), *r_cmax = ar.take<uint32_t>(rows);
@@ -939,6 +979,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
   uint64_t *a_p0 = short_aux ? ar.take<uint64_t>(A->nnz) : nullptr;
   uint32_t *a_len = short_aux ? ar.take<uint32_t>(A->nnz) : nullptr;
+  uint64_t *a_pk = short_pk ? ar.take<uint64_t>(A->nnz) : nullptr;
   ctx->r_nprod_prof = r_nprod;
   ctx->plan_gcnt = r_gcnt;
   ctx->launches.clear();
@@ -950,7 +991,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
   HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
 
-  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same, a_p0, a_len};
+  AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same, a_p0, a_len, a_pk};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
                      A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
   if (max_long > 1 || A->nnz > ctx->long_len)
@@ -983,7 +1024,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   // kernel (whose largest tables leave room for two wavefronts per CU) for the slice kernel
   const uint32_t hash_num_max = (b_sorted && ctx->big_rows) ? ctx->hash_num_slice : 4096u;
   RowMeta rm{r_cmin, r_cmax, r_key, t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), r_nnz, r_numkey, r_gcnt, r_lead,
-             hash_num_max, a_p0, a_len};
+             hash_num_max, a_p0, a_len, a_pk};
 
   for (int key = 0; key < SYM_NBINS; ++key) {
     uint64_t cnt64 = boff[key + 1] - boff[key];
@@ -1080,7 +1121,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.r_cmin = r_cmin; pl.r_cmax = r_cmax; pl.r_nnz = r_nnz;
   pl.r_key = r_key; pl.r_numkey = r_numkey; pl.t_off = t_off; pl.perm = perm;
   pl.r_gcnt = r_gcnt; pl.r_lead = r_lead;
-  pl.a_p0 = a_p0; pl.a_len = a_len;
+  pl.a_p0 = a_p0; pl.a_len = a_len; pl.a_pk = a_pk;
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
   pl.b_sorted = b_sorted;
@@ -1152,7 +1193,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
   RowMeta rm{pl.r_cmin, pl.r_cmax, pl.r_key, pl.t_off, reinterpret_cast<uint32_t *>(ctx->temp_cols.p), pl.r_nnz,
-             pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u, pl.a_p0, pl.a_len};
+             pl.r_numkey, pl.r_gcnt, pl.r_lead, 4096u, pl.a_p0, pl.a_len, pl.a_pk};
   NumOut no{d_row_ptr, d_col, d_val, zero_count};
   const uint32_t hw_order = ctx->hw_lane_order && ctx->lane_order_adds ? 1u : 0u;
   const size_t lds_max = 160 * 1024;
@@ -1181,7 +1222,8 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       const uint32_t wpb = pick_wpb(region);
       TRY(ensure_colcdf(ctx, B));
-      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift)};
+      if (pl.a_pk) TRY(ensure_prec(ctx, B));
+      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
       hipLaunchKernelGGL(log2pm <= 8 ? k_num_short<4> : k_num_short<SH_STEPS>, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),

@@ -1,5 +1,4 @@
 set -o pipefail
-for t in 256 512; do
-SPGEMM_AMD_LIB=$PWD/build_var/libt$t.so bash tools/run2.sh | grep symbolic
-SPGEMM_AMD_LIB=$PWD/build_var/libt$t.so timeout -k 10 300 python -u -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py -m gpu -x -q --timeout 200 --timeout-method thread 2>&1 | tail -2
-done
+timeout -k 10 250 python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port 29611 tests/_dist_gpu_worker.py > gpurun_out/dist4.log 2>&1
+echo rc=$?
+grep -n "Error\|error\|Traceback\|File \"/root\|assert" gpurun_out/dist4.log | head -30
