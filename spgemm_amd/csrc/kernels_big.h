@@ -10,10 +10,12 @@ namespace sg {
 // win_words * 32 columns.  Every A entry keeps {position, end} of what is left of its B row (in
 // LDS for rows of up to BIG_CUR entries, else in g_state, two uint64 per entry of A); in a window
 // the part of the B row that falls into it (a "piece": contiguous, the B row is sorted) is ORed
-// into the LDS bitmap and the position moves on.  Pieces are classified by what is left of the B
-// row: up to BIG_MID entries -> one wavefront takes the piece, four pieces at a time, all their
-// loads in flight together; more -> all wavefronts take BIG_THREADS entries of the piece per step,
-// four pieces at a time, and a wavefront stops at its first block that leaves the window.
+// into the LDS bitmap and the position moves on.  One wavefront takes the first BIG_MID entries of
+// a piece, four pieces at a time, all their loads in flight together; a piece whose first BIG_MID
+// entries all lay inside the window goes on: all wavefronts take BIG_THREADS of its entries per
+// step, four such pieces at a time, and a wavefront stops at its first block that leaves the window
+// (handing every B row with more than BIG_MID entries left to all wavefronts at once cost 10 %
+// more on R-MAT 22: most of those pieces have a few dozen entries in a window).
 // The bitmap is then written out in blocks of 256 words (four per lane, the blocks dealt to the
 // wavefronts round robin): block totals, a scan over the blocks, and every lane writes the
 // columns of its own four words, at most 128.
@@ -25,7 +27,11 @@ namespace sg {
 #ifndef SG_BIG_THREADS
 #define SG_BIG_THREADS 512
 #endif
-constexpr uint32_t BIG_THREADS = SG_BIG_THREADS, BIG_WAVES = BIG_THREADS / 64, BIG_CUR = BIG_THREADS, BIG_MID = 256;
+#ifndef SG_BIG_MID
+#define SG_BIG_MID 256
+#endif
+constexpr uint32_t BIG_THREADS = SG_BIG_THREADS, BIG_WAVES = BIG_THREADS / 64, BIG_CUR = BIG_THREADS, BIG_MID = SG_BIG_MID;
+constexpr int BIG_MID_LOADS = BIG_MID / 64; // loads per lane that cover the first BIG_MID entries of a piece
 static_assert(BIG_CUR == BIG_THREADS, "a batch of A entries is one entry per thread, and the piece lists hold one batch");
 constexpr uint32_t BIG_WIN_MAX = 32 * BIG_THREADS;        // words of the largest window
 constexpr uint32_t BIG_BPW = BIG_WIN_MAX / 256 / BIG_WAVES; // blocks of 256 words per wavefront and window
@@ -33,7 +39,8 @@ __host__ __device__ inline size_t sym_big_lds(uint32_t win_words) {
   return (size_t)win_words * 4 + (size_t)BIG_CUR * (8 + 8 + 4 + 4 + 4) + (size_t)(win_words / 64) * 4;
 }
 
-__global__ void __launch_bounds__(BIG_THREADS)
+// two workgroups per CU: 2 * BIG_WAVES / 4 wavefronts per SIMD have to fit the register file
+__global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(2 * BIG_WAVES / 4, 2 * BIG_WAVES / 4)))
     k_sym_big(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t win_words,
               uint64_t *__restrict__ g_state, uint64_t nnz_a, unsigned long long *__restrict__ stamps) {
 #ifdef SG_SYM_STAMPS
@@ -89,47 +96,52 @@ __global__ void __launch_bounds__(BIG_THREADS)
           p = pos[idx];
           e = end[idx];
         }
-        const uint64_t rem = e - p;
-        if (rem > BIG_MID) {
-          const uint32_t slot = atomicAdd(&s_n[1], 1u);
-          s_long[slot] = idx;
-          s_cnt[slot] = 0u;
-        } else if (rem) {
-          s_mid[atomicAdd(&s_n[0], 1u)] = idx;
-        }
+        if (e - p) s_mid[atomicAdd(&s_n[0], 1u)] = idx;
       }
       SY_STAMP(0)
       __syncthreads();
       SY_STAMP(1)
-      const uint32_t nmid = s_n[0], nlong = s_n[1];
-      // mid pieces: a wavefront takes four pieces and all of their (up to 4 x 64) entries at once
+      const uint32_t nmid = s_n[0];
+      // first BIG_MID entries of every piece: a wavefront takes four pieces and all of their (up to
+      // 4 x BIG_MID) entries at once.  (Fetching the next four pieces while these are ORed in needs
+      // more than the 128 registers two workgroups per CU leave, and runs at half the speed.)
       for (uint32_t e0 = wv * 4u; e0 < nmid; e0 += BIG_WAVES * 4u) {
-        uint32_t id[4], c[4][4];
-        uint64_t p[4];
+        uint32_t id[4], c[4][BIG_MID_LOADS];
+        uint64_t p[4], full[4];
         uint32_t rem[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const bool on = e0 + u < nmid;
           id[u] = s_mid[on ? e0 + u : e0];
           p[u] = pos[id[u]];
-          rem[u] = on ? (uint32_t)(end[id[u]] - p[u]) : 0u;
+          full[u] = on ? end[id[u]] - p[u] : 0ull;
+          rem[u] = (uint32_t)min(full[u], (uint64_t)BIG_MID);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) c[u][j] = (64u * j + lane < rem[u]) ? B.col[p[u] + 64u * j + lane] : EMPTY_KEY;
+          for (int j = 0; j < BIG_MID_LOADS; ++j) c[u][j] = (64u * j + lane < rem[u]) ? B.col[p[u] + 64u * j + lane] : EMPTY_KEY;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           uint32_t took = 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < BIG_MID_LOADS; ++j) {
             const bool in = 64u * j + lane < rem[u] && (last || (uint64_t)c[u][j] < chi);
             if (in) atomicOr(&bits[(c[u][j] >> 5) - wb], 1u << (c[u][j] & 31u));
             took += (uint32_t)__popcll(__ballot(in));
           }
-          if (lane == 0 && rem[u]) pos[id[u]] = p[u] + took;
+          if (lane == 0 && rem[u]) {
+            pos[id[u]] = p[u] + took;
+            if (took == BIG_MID && full[u] > BIG_MID) { // all of it lay in the window and the B row goes on
+              const uint32_t slot = atomicAdd(&s_n[1], 1u);
+              s_long[slot] = id[u];
+              s_cnt[slot] = 0u;
+            }
+          }
         }
       }
+      __syncthreads(); // the list of pieces that go on, and their positions
+      const uint32_t nlong = s_n[1];
       SY_STAMP(2)
       // long pieces: all wavefronts, 1024 entries of a piece per step, four pieces at a time
       for (uint32_t e0 = 0; e0 < nlong; e0 += 4u) {

@@ -1,4 +1,3 @@
 set -o pipefail
-timeout -k 10 250 python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port 29611 tests/_dist_gpu_worker.py > gpurun_out/dist4.log 2>&1
-echo rc=$?
-grep -n "Error\|error\|Traceback\|File \"/root\|assert" gpurun_out/dist4.log | head -30
+bash tools/run2.sh "$@" | grep symbolic || exit 1
+timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/t4.log 2>&1; rc=$?; tail -3 gpurun_out/t4.log; [ $rc -eq 0 ] || exit $rc
