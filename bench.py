@@ -69,7 +69,27 @@ def measured_traffic(workload, kernel):
     match = [v for name, v in kernels.items() if name == kernel or name.startswith(kernel + "<")]
     if not match:
         return None, None
-    return max(m["hbm_bytes"] for m in match), os.path.relpath(files[-1], ROOT)
+    best = max(match, key=lambda m: m["hbm_bytes"])
+    measured_traffic.counters = best.get("sq")
+    return best["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+
+
+measured_traffic.counters = None
+
+
+def issue_bounds(sq, kernel_ms, n_cu=256, clock_ghz=2.4):
+    """Lower bounds on a kernel's time from what it issues, out of the committed SQ counters of the
+    same launch: every vector instruction holds one of the 4 * n_cu SIMDs for 4 cycles, every LDS-array
+    cycle one of the n_cu LDS units.  The clock is the peak one, so the bounds are optimistic."""
+    if not sq:
+        return None
+    valu_ms = sq["SQ_INSTS_VALU"] * 4.0 / (4 * n_cu) / (clock_ghz * 1e6)
+    lds_ms = sq["SQ_LDS_IDX_ACTIVE"] / n_cu / (clock_ghz * 1e6)
+    return {"valu_issue_ms": valu_ms, "lds_array_ms": lds_ms, "valu_frac_of_kernel_time": valu_ms / kernel_ms,
+            "lds_frac_of_kernel_time": lds_ms / kernel_ms, "valu_wave_instructions": sq["SQ_INSTS_VALU"],
+            "lds_bank_conflict_share": sq["SQ_LDS_BANK_CONFLICT"] / max(sq["SQ_LDS_IDX_ACTIVE"], 1.0),
+            "assumed_clock_GHz": clock_ghz,
+            "note": "second bound: time the kernel's own vector instructions / LDS cycles need at peak clock"}
 
 
 def kernel_name(launch):
@@ -210,6 +230,9 @@ def run_single(args):
                              "hbm_rate_frac_of_peak": hbm_rate / HBM_PEAK_GBS,
                              "limited_by": ("hbm" if copy_gbs and hbm_rate > 0.6 * copy_gbs else
                                             "instruction issue and LDS, not HBM (measured HBM rate well below the copy rate)")})
+            ib = issue_bounds(measured_traffic.counters, dom["ms"])
+            if ib:
+                roofline["issue_bound"] = ib
     b_all = st["bytes_algorithmic"]
     bc_all = compulsory_bytes(st["nnz_a"], st["nnz_c"], st["rows_a"])
     sec_all = ms_per_step * 1e-3

@@ -95,6 +95,9 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   short-row kernels (count-only symbolic pass, numeric
  *                                                   pass that sorts the row's products itself); 0: none
  *   short_rpw                                       rows one wavefront of those kernels pipelines
+ *   grp_compact                                     row-group numeric kernel: 1 two-level bitmap over
+ *                                                   the column hull (less LDS), 0 flat bitmap (fewer
+ *                                                   instructions), 2 (default) chosen per launch
  *   short_packed                                    1 (default): the numeric one reads the rows of B
  *                                                   as 16-byte {column, value} records padded to
  *                                                   128-byte lines (built once per B handle, at most

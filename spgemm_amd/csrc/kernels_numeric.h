@@ -98,10 +98,30 @@ __global__ void __launch_bounds__(256)
 // A that share their column list.  Every B entry is loaded once and its output position is found
 // once; it is then multiplied by each row's own A value (staged in LDS) and added to that row's
 // accumulator.  Each row still receives its products in the order of its A row, as on the CPU.
-// LDS per wavefront: bmp[words] {bits, prefix} | vals[gmax][cap] | avals[gmax][alen], with
-// (gmax, alen) = (GRP_MAX, GRP_ALEN) for TIER 0, (GRP_MAX_WIDE, GRP_ALEN_MID) for TIER 1 and
-// (GRP_MAX_WIDE, GRP_ALEN_WIDE) for TIER 2.
-template <int TIER>
+// Column -> output position, two forms:
+// COMPACT = false: a flat bitmap over the row's column hull, {bits, outputs before} per 32 columns;
+//   a look-up is one 8-byte LDS read and a population count.
+// COMPACT = true: a bitmap in two levels, for a hull that is wide and almost empty (a 3-D stencil:
+//   375 outputs in a hull of 65,536 columns, where the flat bitmap is 16 KiB of a 31-KiB region and
+//   the LDS a wavefront takes decides how many of them a CU holds): top[] has one bit per 32-column
+//   word of the hull that holds an output, with the count of such words before it; cw[] holds those
+//   words only ({bits, outputs before the word}).  A look-up is two dependent 8-byte LDS reads and
+//   two population counts.  dielFilterV3real-like rows: 8 instead of 5 wavefronts per CU, 13.6 ms
+//   instead of 20.0; af_shell10-like rows (hull of 16,384 columns, kernel bound by instruction
+//   issue): 3.6 ms instead of 3.2, so the host picks the form per launch (grp_use_compact).
+// LDS per wavefront: bitmap (flat: bmp[words]; compact: top[grp_top_words(words)] | cw[cap]) |
+// vals[gmax][cap] | avals[gmax][alen], with (gmax, alen) = (GRP_MAX, GRP_ALEN) for TIER 0,
+// (GRP_MAX_WIDE, GRP_ALEN_MID) for TIER 1 and (GRP_MAX_WIDE, GRP_ALEN_WIDE) for TIER 2.
+__host__ __device__ inline uint32_t grp_top_words(uint32_t words) { return (words + 31u) / 32u; }
+__host__ __device__ inline size_t grp_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
+  const size_t bitmap = compact ? (size_t)grp_top_words(words) * 8u + (size_t)cap * 8u : (size_t)words * 8u;
+  return bitmap + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
+}
+// the two-level form where the flat bitmap would be more than a third of the wavefront's LDS
+__host__ __device__ inline bool grp_use_compact(uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
+  return (size_t)words * 8u * 3u > grp_region(false, words, cap, gmax, alen);
+}
+template <int TIER, bool COMPACT>
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
                      uint32_t words, uint32_t cap, uint32_t wpb) {
@@ -112,10 +132,13 @@ __global__ void __launch_bounds__(256)
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (w >= wpb || idx >= nrows) return;
-  const size_t region = (size_t)words * 8u + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
-  uint64_t *bmp = reinterpret_cast<uint64_t *>(smem + w * region);
-  uint32_t *bmp32 = reinterpret_cast<uint32_t *>(bmp);
-  double *vals = reinterpret_cast<double *>(bmp + words);
+  const size_t region = grp_region(COMPACT, words, cap, gmax, alen);
+  const uint32_t topw = COMPACT ? grp_top_words(words) : 0u;
+  uint64_t *top = reinterpret_cast<uint64_t *>(smem + w * region); // {words with an output (bits), such words before}
+  uint32_t *top32 = reinterpret_cast<uint32_t *>(top);
+  uint64_t *cw = top + topw; // compact: {outputs in the word (bits), outputs before} of the words with outputs; flat: of all words
+  uint32_t *cw32 = reinterpret_cast<uint32_t *>(cw);
+  double *vals = reinterpret_cast<double *>(cw + (COMPACT ? cap : words));
   double *avals = vals + (size_t)gmax * cap;
   // row state through the scalar unit (all of it was written by earlier kernels)
   const uint32_t row = scalar_view(rows)[idx];
@@ -134,7 +157,13 @@ __global__ void __launch_bounds__(256)
     my_off = o.c_ptr[row + lane];
     my_a = A.ptr[row + lane];
   }
-  for (uint32_t i = lane; i < nw; i += 64) bmp[i] = 0ull;
+  const uint32_t ntop = (nw + 31u) >> 5;
+  if constexpr (COMPACT) {
+    for (uint32_t i = lane; i < ntop; i += 64) top[i] = 0ull;
+    for (uint32_t i = lane; i < n; i += 64) cw[i] = 0ull; // at most one word per output
+  } else {
+    for (uint32_t i = lane; i < nw; i += 64) cw[i] = 0ull;
+  }
 #pragma unroll
   for (uint32_t j = 0; j < GRP_MAX; ++j) {
     if (j < cnt) {
@@ -149,23 +178,47 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (uint32_t j = 0; j < GRP_MAX; ++j)
       if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
-    uint32_t cc = c - base;
-    atomicOr(&bmp32[(cc >> 5) * 2u], 1u << (cc & 31u));
+    const uint32_t cc = c - base, wi = cc >> 5;
+    if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
+    else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
   }
   lds_fence();
+  uint32_t ncw = nw;
+  // index in cw[] of the 32-column word wi (compact: a word that holds an output)
+  auto compact_word = [&](uint32_t wi) {
+    if constexpr (!COMPACT) return wi;
+    const uint64_t t = top[wi >> 5];
+    return (uint32_t)(t >> 32) + __popc((uint32_t)t & ((1u << (wi & 31u)) - 1u));
+  };
+  if constexpr (COMPACT) {
+    ncw = 0;
+    for (uint32_t r0 = 0; r0 < ntop; r0 += 64) {
+      const uint32_t ti = r0 + lane;
+      const uint32_t pc = ti < ntop ? __popc(top32[ti * 2u]) : 0u;
+      const uint32_t incl = group_incl_scan<64>(pc);
+      if (ti < ntop) top32[ti * 2u + 1u] = ncw + incl - pc;
+      ncw += group_last<64>(incl);
+    }
+    lds_fence();
+    for (uint32_t p = lane; p < n; p += 64) {
+      const uint32_t cc = tin[p] - base;
+      atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
+    }
+    lds_fence();
+  }
   uint32_t carry = 0;
-  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
-    uint32_t wi = r0 + lane;
-    uint32_t pc = wi < nw ? __popc(bmp32[wi * 2u]) : 0u;
-    uint32_t incl = group_incl_scan<64>(pc);
-    if (wi < nw) bmp32[wi * 2u + 1u] = carry + incl - pc;
+  for (uint32_t r0 = 0; r0 < ncw; r0 += 64) {
+    const uint32_t ci = r0 + lane;
+    const uint32_t pc = ci < ncw ? __popc(cw32[ci * 2u]) : 0u;
+    const uint32_t incl = group_incl_scan<64>(pc);
+    if (ci < ncw) cw32[ci * 2u + 1u] = carry + incl - pc;
     carry += group_last<64>(incl);
   }
   lds_fence();
   walk.run(A, B, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
-    uint32_t cc = c - base;
-    uint64_t e = bmp[cc >> 5];
-    uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+    const uint32_t cc = c - base;
+    const uint64_t e = cw[compact_word(cc >> 5)];
+    const uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
     for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * alen + apos], bv));
   });
   lds_fence();

@@ -101,6 +101,7 @@ struct spgemm_ctx {
   bool hw_lane_order = false;    // this device passed k_probe_lane_order when the context was made
   uint32_t lane_order_adds = 1;  // option: 0 = never rely on it (claim rounds instead)
   uint32_t slice_queues = 1;     // work queues of the slice kernel (8: one per XCD; 1: one for the device)
+  uint32_t grp_compact = 2;      // row-group numeric kernel: two-level bitmap (1), flat (0), chosen per launch (2)
   uint32_t short_packed = 1;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
@@ -377,7 +378,8 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
-  raise_lds_limit(k_num_window_grp<0>); raise_lds_limit(k_num_window_grp<1>); raise_lds_limit(k_num_window_grp<2>);
+  raise_lds_limit(k_num_window_grp<0, false>); raise_lds_limit(k_num_window_grp<1, false>); raise_lds_limit(k_num_window_grp<2, false>);
+  raise_lds_limit(k_num_window_grp<0, true>); raise_lds_limit(k_num_window_grp<1, true>); raise_lds_limit(k_num_window_grp<2, true>);
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
@@ -627,6 +629,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "slice_queues") {
     if (value < 1 || value > (int64_t)SLICE_MAX_QUEUES) return fail(SPGEMM_ERR_INVALID, "slice_queues must be 1..8");
     ctx->slice_queues = (uint32_t)value;
+  } else if (n == "grp_compact") {
+    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "grp_compact must be 0, 1 or 2");
+    ctx->grp_compact = (uint32_t)value;
   } else if (n == "short_packed") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0 or 1");
     ctx->short_packed = (uint32_t)value;
@@ -1209,11 +1214,14 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : 512u;
       const uint32_t gmax = tier ? GRP_MAX_WIDE : GRP_MAX;
       const uint32_t alen = tier == 0 ? GRP_ALEN : tier == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
-      size_t region = (size_t)words * 8 + (size_t)gmax * cap * 8 + (size_t)gmax * alen * 8;
+      const bool compact = ctx->grp_compact == 2 ? grp_use_compact(words, cap, gmax, alen) : ctx->grp_compact != 0;
+      size_t region = grp_region(compact, words, cap, gmax, alen);
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       uint32_t wpb = pick_wpb(region);
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
-      hipLaunchKernelGGL(tier == 0 ? k_num_window_grp<0> : tier == 1 ? k_num_window_grp<1> : k_num_window_grp<2>,
+      auto kern = compact ? (tier == 0 ? k_num_window_grp<0, true> : tier == 1 ? k_num_window_grp<1, true> : k_num_window_grp<2, true>)
+                          : (tier == 0 ? k_num_window_grp<0, false> : tier == 1 ? k_num_window_grp<1, false> : k_num_window_grp<2, false>);
+      hipLaunchKernelGGL(kern,
                          dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb);
     } else if (key >= NUM_HASH0 && key < NUM_GLOBAL && (key & 3) == 0) { // short rows

@@ -36,6 +36,7 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
         return largest(glob.glob(f"{wdir}/{name}/**/*counter_collection.csv", recursive=True)[0])
 
     rd, wr, fe, wq = f("rdreq"), f("write"), f("fetch"), f("wrreq")
+    sq = f("sq") if os.path.isdir(os.path.join(wdir, "sq")) else {}
     out = {}
     for k in rd:
         if not k.startswith("sg::k_"):
@@ -49,6 +50,8 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
             "TCC_EA0_RDREQ": n, "TCC_EA0_RDREQ_128B": n128, "TCC_EA0_RDREQ_32B": n32,
             "TCC_EA0_WRREQ": wq.get(k, {}).get("TCC_EA0_WRREQ_sum"), "TCC_EA0_WRREQ_64B": wq.get(k, {}).get("TCC_EA0_WRREQ_64B_sum"),
             "TCC_HIT": wq.get(k, {}).get("TCC_HIT_sum"), "TCC_MISS": wq.get(k, {}).get("TCC_MISS_sum"), "grid": rd[k]["_grid"]}
+        if k in sq:  # wave-instructions issued and LDS-array cycles of the same launch
+            out[k.replace("sg::", "")]["sq"] = {c: v for c, v in sq[k].items() if c != "_grid"}
     json.dump({"workload": w,
                "command": f"rocprofv3 --pmc <one counter group per run> -- python3 bench.py --workload {w} --steps 1 --warmup 0 --no-cpu-baseline",
                "kernels": out}, open(f"profiles/{tag}_traffic_{w}.json", "w"), indent=1)
