@@ -6,14 +6,19 @@
 namespace sg {
 
 // ---- symbolic, window path: one wavefront per row ------------------------------------------------
-// LDS per wavefront: `words` pairs {bitmap word, number of set bits before it} covering columns
-// [cmin & ~31, cmax].
+// LDS per wavefront: a bitmap of `words` 32-bit words covering columns [cmin & ~31, cmax] and, per
+// word, the number of set bits before it as 16 bits (6 bytes per word: the LDS per wavefront sets
+// how many of them a CU holds, and a hull of 65,536 columns went from 9 to 13 wavefronts per CU).
 //
 // Every product ORs its bit into the bitmap (lanes of one instruction that share a word are
 // serialised by the LDS; combining them first in registers was measured and cost more than it
 // saved).  The sorted column list is then written coalesced: output position p finds the word
 // that holds the p-th set bit by a binary search over the per-word prefix counts.
 // FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
+// LDS per wavefront: bits u32[words] | prefix u16[words] (rounded up to 16 bytes) | flat-walk scratch
+__host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
+  return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
+}
 template <bool FLAT>
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
@@ -23,42 +28,45 @@ __global__ void __launch_bounds__(256)
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform on the scalar unit
   uint32_t idx = xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
   if (idx >= nrows) return;
-  const size_t region = (size_t)words * 8u + (FLAT ? FLAT_BYTES : 0u);
-  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);
+  const size_t region = sym_window_region(words, FLAT);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);             // words x 32 columns
+  uint16_t *pre = reinterpret_cast<uint16_t *>(smem + w * region + (size_t)words * 4u); // set bits before each word
   const uint32_t row = rows[idx];
   const uint32_t base = m.cmin[row] & ~31u;
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
-  for (uint32_t i = lane; i < nw; i += 64) reinterpret_cast<uint64_t *>(bm)[i] = 0ull;
+  for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
   lds_fence();
   auto mark = [&](uint32_t col, double, double, uint32_t) {
     if (col == EMPTY_KEY) return;
     uint32_t c = col - base;
-    atomicOr(&bm[(c >> 5) * 2u], 1u << (c & 31u));
+    atomicOr(&bm[c >> 5], 1u << (c & 31u));
   };
-  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + (size_t)words * 8u, mark);
+  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + sym_window_region(words, false), mark);
   else wave_row_walk<false>(A, B, row, lane, mark);
   lds_fence();
-  // per-word prefix of the set-bit counts
+  // per-word prefix of the set-bit counts (16 bits: the hull of the window path is at most 65,536
+  // columns wide, so fewer than 65,536 bits lie before any word)
   uint32_t carry = 0;
   for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
     uint32_t wi = r0 + lane;
-    uint32_t pc = wi < nw ? __popc(bm[wi * 2u]) : 0u;
+    uint32_t pc = wi < nw ? __popc(bm[wi]) : 0u;
     uint32_t incl = group_incl_scan<64>(pc);
-    if (wi < nw) bm[wi * 2u + 1u] = carry + incl - pc;
+    if (wi < nw) pre[wi] = (uint16_t)(carry + incl - pc);
     carry += group_last<64>(incl);
   }
   lds_fence();
-  // output position p -> word holding the p-th set bit (binary search on the prefixes) -> column
+  // output position p -> word holding the p-th set bit (binary search on the prefixes) -> column.
+  // Empty words repeat the prefix of the word after them; the search takes the last word whose
+  // prefix is <= p, which is the one that holds the bit.
   const uint32_t n = carry;
   uint32_t *out = m.temp_cols + m.t_off[row];
   for (uint32_t p = lane; p < n; p += 64) {
     uint32_t lo = 0, hi = nw - 1u;
     while (lo < hi) {
       uint32_t mid = (lo + hi + 1u) >> 1;
-      if (bm[mid * 2u + 1u] <= p) lo = mid; else hi = mid - 1u;
+      if ((uint32_t)pre[mid] <= p) lo = mid; else hi = mid - 1u;
     }
-    uint2 e = *reinterpret_cast<const uint2 *>(&bm[lo * 2u]);
-    out[p] = base + (lo << 5) + select_bit(e.x, p - e.y);
+    out[p] = base + (lo << 5) + select_bit(bm[lo], p - (uint32_t)pre[lo]);
   }
   // the group's rows share the pattern: same nnz; they are accumulated together when the group
   // kernel has a tier for them, else one by one (each reading the leader's column list)

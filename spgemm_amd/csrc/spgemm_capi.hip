@@ -1040,7 +1040,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t tier = key >> 2;
       uint32_t words = (64u << tier) + 2u;
       const bool flat = (key & 3) < 3 && ctx->flat_walk; // short B rows: products laid end to end over the lanes
-      size_t region = (size_t)words * 8 + (flat ? FLAT_BYTES : 0);
+      size_t region = sym_window_region(words, flat);
       uint32_t wpb = pick_wpb(region);
       st.rows_window += cnt;
       TRY(prof_begin(ctx, 0, 0, flat ? 0 : 64, cnt, words, 0, region * wpb, rows_bin));
