@@ -289,7 +289,16 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                        mb->d_rowinfo);
     HIP_TRY(hipGetLastError());
-    // where the padded records of every row would start (the records themselves: ensure_prec)
+  }
+  return SPGEMM_OK;
+}
+
+// Where the padded records of every row of B would start (the records themselves: ensure_prec),
+// into the second half of the row-info records.  Only for a B that short rows of A may refer to.
+static int ensure_prec_layout(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_prow || !B->rows) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  {
     const size_t b_start = align_up((B->rows + 1) * 8, 256), b_part = align_up(((size_t)scan_parts(B->rows) + 2) * 8, 256);
     TRY(pool_alloc(ctx, b_start + b_part + B->rows * 4, (void **)&mb->d_prow, &mb->bytes_prow));
     uint64_t *partial = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mb->d_prow) + b_start);
@@ -961,7 +970,11 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   need += align_up((MAX_BINS + 1) * 8, 256) + NPROD_SLOTS * 8 + 256 + 256; // bin_off, counters
   need += align_up((32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE) * 8, 256);  // zero count, flags, work queues of the slice kernel
   const bool short_aux = ctx->cp.short_max_nprod > 0;
-  const bool short_pk = short_aux && ctx->short_packed;
+  // padded records of B's rows: only where short rows are likely at all (mean products per row of A
+  // within twice the short-row limit); without them the short-row kernel reads B's own arrays
+  const double mean_prod = (double)A->nnz / (double)std::max<uint64_t>(A->rows, 1) * (double)B->nnz / (double)std::max<uint64_t>(B->rows, 1);
+  const bool short_pk = short_aux && ctx->short_packed && (B->d_prow || mean_prod <= 2.0 * ctx->cp.short_max_nprod);
+  if (short_pk) TRY(ensure_prec_layout(ctx, B));
   if (short_aux) need += align_up(A->nnz * 8, 256) + align_up(A->nnz * 4, 256); // short rows: B row start and length per A entry
   if (short_pk) need += align_up(A->nnz * 8, 256);                               // ... and the start of its padded records
   TRY(grow(ctx, ctx->arena, need));
