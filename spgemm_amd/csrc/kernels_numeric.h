@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(256)
 // vals[gmax][cap] | avals[gmax][alen], with (gmax, alen) = (GRP_MAX, GRP_ALEN) for TIER 0,
 // (GRP_MAX_WIDE, GRP_ALEN_MID) for TIER 1 and (GRP_MAX_WIDE, GRP_ALEN_WIDE) for TIER 2.
 __host__ __device__ inline uint32_t grp_top_words(uint32_t words) { return (words + 31u) / 32u; }
+// gmax: rows a group of the launch has at most (from the analysis, <= GRP_MAX / GRP_MAX_WIDE)
 __host__ __device__ inline size_t grp_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
   const size_t bitmap = compact ? (size_t)grp_top_words(words) * 8u + (size_t)cap * 8u : (size_t)words * 8u;
   return bitmap + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
@@ -124,8 +125,7 @@ __host__ __device__ inline bool grp_use_compact(uint32_t words, uint32_t cap, ui
 template <int TIER, bool COMPACT>
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
-                     uint32_t words, uint32_t cap, uint32_t wpb) {
-  constexpr uint32_t gmax = TIER ? GRP_MAX_WIDE : GRP_MAX;
+                     uint32_t words, uint32_t cap, uint32_t wpb, uint32_t gmax) {
   constexpr uint32_t alen = TIER == 0 ? GRP_ALEN : TIER == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;

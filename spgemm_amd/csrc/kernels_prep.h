@@ -244,33 +244,41 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     k_group(uint32_t rows, const uint64_t *__restrict__ a_ptr, const uint8_t *__restrict__ same,
             uint8_t *__restrict__ key, uint32_t *__restrict__ ub, uint8_t *__restrict__ gcnt,
-            uint32_t *__restrict__ lead, uint32_t enable) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  lead[i] = i;
-  const uint32_t k = key[i];
-  const uint64_t len = a_ptr[i + 1] - a_ptr[i];
-  if (!enable || k >= (uint32_t)SYM_HASH0 || len > GRP_ALEN_WIDE) { // not a window row (or no products)
-    gcnt[i] = 1;
-    return;
+            uint32_t *__restrict__ lead, uint32_t enable, uint32_t *__restrict__ gmax_seen) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t c = 0;    // rows of the group this row leads (0: leads none that counts for the LDS sizing)
+  bool wide = false;
+  if (i < rows) {
+    lead[i] = i;
+    const uint32_t k = key[i];
+    const uint64_t len = a_ptr[i + 1] - a_ptr[i];
+    uint32_t g = 1; // gcnt of the row
+    if (enable && k < (uint32_t)SYM_HASH0 && len <= GRP_ALEN_WIDE) { // a window row with products
+      uint32_t pos = 0; // rows before i that belong to the same run
+      while (pos < 56u && pos < i && same[i - pos]) ++pos;
+      if (pos < 56u) {
+        const uint32_t gmax = group_max_rows(len); // the rows of a run have the same length
+        if (pos % gmax != 0) { // follower: handled by its leader
+          g = 0;
+          key[i] = (uint8_t)KEY_NONE;
+          ub[i] = 0;
+          lead[i] = i - pos % gmax;
+        } else {
+          while (g < gmax && i + g < rows && same[i + g]) ++g;
+          c = g;
+          wide = len > GRP_ALEN;
+        }
+      }
+    }
+    gcnt[i] = (uint8_t)g;
   }
-  uint32_t pos = 0; // rows before i that belong to the same run
-  while (pos < 56u && pos < i && same[i - pos]) ++pos;
-  if (pos >= 56u) {
-    gcnt[i] = 1;
-    return;
+  // largest group of the multiply, narrow ([0]) and wide ([1]) rows apart: the group kernel sizes its
+  // LDS by it (five unknowns per mesh node make groups of five, not of GRP_MAX)
+  const uint32_t mn = group_max<64>(wide ? 0u : c), mw = group_max<64>(wide ? c : 0u);
+  if ((threadIdx.x & 63u) == 0) {
+    if (mn > gmax_seen[0]) atomicMax(&gmax_seen[0], mn); // the plain read only saves atomics
+    if (mw > gmax_seen[1]) atomicMax(&gmax_seen[1], mw);
   }
-  const uint32_t gmax = group_max_rows(len); // the rows of a run have the same length
-  if (pos % gmax != 0) { // follower: handled by its leader
-    gcnt[i] = 0;
-    key[i] = (uint8_t)KEY_NONE;
-    ub[i] = 0;
-    lead[i] = i - pos % gmax;
-    return;
-  }
-  uint32_t c = 1;
-  while (c < gmax && i + c < rows && same[i + c]) ++c;
-  gcnt[i] = (uint8_t)c;
 }
 
 // ---- exclusive scan (uint32 in, uint64 out), three launches ----------------------------------

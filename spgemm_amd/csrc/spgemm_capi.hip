@@ -150,6 +150,7 @@ struct spgemm_ctx {
     bool num_ready = false;          // the three fields below are valid
     uint64_t num_boff[MAX_BINS + 1]; // start of every numeric bin in `perm`
     uint32_t max_len_big = 0;        // longest A row among the big rows
+    uint32_t gmax_narrow = GRP_MAX, gmax_wide = GRP_MAX_WIDE; // largest row group among rows of up to GRP_ALEN entries / longer
     bool b_sorted = false; // every B row has strictly increasing columns
   } plan;
   size_t arena_used = 0;
@@ -923,6 +924,7 @@ struct HostCounts {
   uint64_t total_a; // total_ub (symbolic phase) or nnz (numeric phase)
   uint64_t total_nprod;
   uint32_t long_count;
+  uint32_t gmax_seen[2]; // largest row group: narrow rows, wide rows
   uint32_t b_unsorted;  // B rows whose columns are not strictly increasing
   uint32_t max_len_big; // longest A row among the numeric phase's big rows
   uint32_t pad;
@@ -1016,7 +1018,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     hipLaunchKernelGGL(k_analyze_long, dim3(std::min<uint32_t>(max_long, 1024)), dim3(256), 0, ctx->stream, A->d_ptr,
                        A->d_col, B->d_rowinfo, ao, ctx->cp);
   hipLaunchKernelGGL(k_group, dim3(div_up_u64(rows, 256)), dim3(256), 0, ctx->stream, rows, A->d_ptr, r_same, r_key, r_ub,
-                     r_gcnt, r_lead, ctx->row_groups);
+                     r_gcnt, r_lead, ctx->row_groups, long_count + 1);
   HIP_TRY(hipGetLastError());
   TRY(launch_scan(ctx, r_ub, rows, t_off, partial));
   PartScratch ps{pblocks, blk_hist, blk_off, partial};
@@ -1027,8 +1029,11 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(hc->nprod_parts, total_nprod, NPROD_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(&hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(hc->gmax_seen, long_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const bool b_sorted = hc->b_unsorted == 0;
+  const uint32_t gmax_narrow = std::min<uint32_t>(std::max<uint32_t>(hc->gmax_seen[0], 1), GRP_MAX);
+  const uint32_t gmax_wide = std::min<uint32_t>(std::max<uint32_t>(hc->gmax_seen[1], 1), GRP_MAX_WIDE);
   st.nprod = 0;
   for (uint32_t i = 0; i < NPROD_SLOTS; ++i) st.nprod += hc->nprod_parts[i];
   const uint64_t total_ub = hc->total_a;
@@ -1140,6 +1145,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.r_key = r_key; pl.r_numkey = r_numkey; pl.t_off = t_off; pl.perm = perm;
   pl.r_gcnt = r_gcnt; pl.r_lead = r_lead;
   pl.a_p0 = a_p0; pl.a_len = a_len; pl.a_pk = a_pk;
+  pl.gmax_narrow = gmax_narrow; pl.gmax_wide = gmax_wide;
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
   pl.b_sorted = b_sorted;
@@ -1225,7 +1231,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, q = (uint32_t)(key - NUM_GRP0) & 3;
       const int tier = q < 2 ? 0 : q == 2 ? 1 : 2; // 0: up to 8 rows; 1, 2: wide groups (see num_key_of)
       uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : 512u;
-      const uint32_t gmax = tier ? GRP_MAX_WIDE : GRP_MAX;
+      const uint32_t gmax = tier ? pl.gmax_wide : pl.gmax_narrow;
       const uint32_t alen = tier == 0 ? GRP_ALEN : tier == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
       const bool compact = ctx->grp_compact == 2 ? grp_use_compact(words, cap, gmax, alen) : ctx->grp_compact != 0;
       size_t region = grp_region(compact, words, cap, gmax, alen);
@@ -1236,7 +1242,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
                           : (tier == 0 ? k_num_window_grp<0, false> : tier == 1 ? k_num_window_grp<1, false> : k_num_window_grp<2, false>);
       hipLaunchKernelGGL(kern,
                          dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
-                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb);
+                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb, gmax);
     } else if (key >= NUM_HASH0 && key < NUM_GLOBAL && (key & 3) == 0) { // short rows
       const uint32_t log2pm = 6 + ((uint32_t)(key - NUM_HASH0) >> 2);
       const size_t region = ((size_t)32 << log2pm) + SH_SCRATCH;
