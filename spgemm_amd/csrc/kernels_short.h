@@ -225,23 +225,32 @@ __global__ void __launch_bounds__(256)
 // 2. The table is read in slot order.  The first entry of a column sums the column's entries one
 //    after the other (they are adjacent) - the CPU's order of additions, bit for bit - and is written
 //    at the position given by the number of column starts before it.
-template <int STEPS>
+// K32: the table entry is 32 bits, column << log2pm | product number, for a B with fewer than
+// 2^(32 - log2pm) columns: half the table, 32-bit atomics and compares.
+__host__ __device__ inline size_t num_short_region(uint32_t log2pm, bool k32) {
+  return ((size_t)(k32 ? 20u : 32u) << log2pm) + SH_SCRATCH;
+}
+template <int STEPS, bool K32>
 __global__ void __launch_bounds__(256)
     k_num_short(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o, ColMap cm,
                 uint32_t log2pm, uint32_t wpb, uint32_t rpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using key_t = typename std::conditional<K32, uint32_t, unsigned long long>::type;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
   if (w >= wpb || first64 >= nrows) return;
   const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
   const uint32_t PM = 1u << log2pm;
-  const size_t region = (size_t)PM * 32u + SH_SCRATCH;
+  const uint32_t cshift = K32 ? log2pm : 32u; // an entry is column << cshift | product number
+  const size_t region = num_short_region(log2pm, K32);
   unsigned char *reg = smem + w * region;
-  unsigned long long *tab = reinterpret_cast<unsigned long long *>(reg);
-  double *prodv = reinterpret_cast<double *>(reg + (size_t)PM * 24u);
-  unsigned char *scratch = reg + (size_t)PM * 32u;
-  constexpr unsigned long long EMPTY64 = ~0ull;
+  key_t *tab = reinterpret_cast<key_t *>(reg);
+  double *prodv = reinterpret_cast<double *>(reg + (size_t)PM * 3u * sizeof(key_t));
+  unsigned char *scratch = reg + (size_t)PM * (3u * sizeof(key_t) + 8u);
+  constexpr key_t EMPTY64 = ~(key_t)0;
+  auto col_of = [&](key_t e) { return (uint32_t)(e >> cshift); };
+  auto q_of = [&](key_t e) { return K32 ? (uint32_t)e & (PM - 1u) : (uint32_t)e; };
   uint32_t nz = 0;
   ShortFetch fa;
   ShortSet<true, STEPS> cur, nxt;
@@ -257,14 +266,19 @@ __global__ void __launch_bounds__(256)
     const uint32_t total = min(cur.total, PM), n = cur.n;
     const uint64_t off = cur.off;
     const uint32_t H = 2u * total, T = (3u * total + 63u) & ~63u; // slots in use: a multiple of 64, <= 3 PM
-    for (uint32_t j = lane * 2u; j < T; j += 128u)
-      *reinterpret_cast<ulonglong2 *>(&tab[j]) = make_ulonglong2(EMPTY64, EMPTY64);
+    if constexpr (K32) {
+      for (uint32_t j = lane * 4u; j < T; j += 256u)
+        *reinterpret_cast<uint4 *>(&tab[j]) = make_uint4(~0u, ~0u, ~0u, ~0u);
+    } else {
+      for (uint32_t j = lane * 2u; j < T; j += 128u)
+        *reinterpret_cast<ulonglong2 *>(&tab[j]) = make_ulonglong2(~0ull, ~0ull);
+    }
     // the row's own column range stretched over the home slots
     const double inv = cm.inv_width;
     const double f_lo = cur.f[0] + (cur.f[1] - cur.f[0]) * ((double)(cur.cmin - ((cur.cmin >> cm.shift) << cm.shift)) * inv);
     const double f_hi = cur.f[2] + (cur.f[3] - cur.f[2]) * ((double)(cur.cmax - ((cur.cmax >> cm.shift) << cm.shift)) * inv);
     const double scale = (double)H / (f_hi - f_lo + 1.0);
-    unsigned long long x[STEPS];
+    key_t x[STEPS];
     uint32_t h[STEPS];
     double fc[STEPS];
 #pragma unroll
@@ -277,7 +291,7 @@ __global__ void __launch_bounds__(256)
       if (cur.c[u] != EMPTY_KEY) {
         const uint32_t q = (uint32_t)u * 64u + lane;
         prodv[q] = __dmul_rn(avs[64u * (i & 1u) + cur.t[u]], cur.bv[u]);
-        x[u] = ((unsigned long long)cur.c[u] << 32) | q;
+        x[u] = ((key_t)cur.c[u] << cshift) | q;
         h[u] = min(H - 1u, (uint32_t)((fc[u] - f_lo) * scale));
       }
     }
@@ -287,7 +301,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
         if (x[u] != EMPTY64) {
-          const unsigned long long old = atomicMin(&tab[h[u]], x[u]);
+          const key_t old = atomicMin(&tab[h[u]], x[u]);
           if (old > x[u]) x[u] = old; // EMPTY64 ends the chain
           ++h[u];
           if (h[u] >= T) x[u] = EMPTY64; // cannot happen: at most `total` entries past the last home slot
@@ -302,21 +316,23 @@ __global__ void __launch_bounds__(256)
     const bool plain = n == total; // no column twice: every entry is its own output
     for (uint32_t s0 = 0; s0 < T; s0 += 64u) {
       const uint32_t sl = s0 + lane;
-      const unsigned long long e = tab[sl];
-      const uint32_t col = (uint32_t)(e >> 32);
+      const key_t e = tab[sl];
+      const uint32_t col = col_of(e);
       const bool occ = e != EMPTY64;
       // a column starts where the slot before holds another column or nothing (an empty slot reads as
       // column 0xFFFFFFFF, which no entry has)
-      const uint32_t prev_col = (sl && !plain) ? reinterpret_cast<const uint32_t *>(tab)[2u * (sl - 1u) + 1u] : EMPTY_KEY;
+      // (an empty slot reads as the largest column there is under either width, which no entry has:
+      // with 32-bit entries B has fewer than 2^(32 - log2pm) columns)
+      const uint32_t prev_col = (sl && !plain) ? col_of(tab[sl - 1u]) : col_of(EMPTY64);
       const bool start = occ && prev_col != col;
       const uint64_t bal = __ballot(start);
       if (start) {
-        double v = prodv[(uint32_t)e];
+        double v = prodv[q_of(e)];
         if (!plain)
           for (uint32_t j = sl + 1u; j < T; ++j) {
-            const unsigned long long g = tab[j];
-            if ((uint32_t)(g >> 32) != col || g == EMPTY64) break;
-            v += prodv[(uint32_t)g];
+            const key_t g = tab[j];
+            if (col_of(g) != col || g == EMPTY64) break;
+            v += prodv[q_of(g)];
           }
         const uint32_t pp = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (pp < n) {

@@ -102,6 +102,7 @@ struct spgemm_ctx {
   uint32_t lane_order_adds = 1;  // option: 0 = never rely on it (claim rounds instead)
   uint32_t slice_queues = 1;     // work queues of the slice kernel (8: one per XCD; 1: one for the device)
   uint32_t grp_compact = 2;      // row-group numeric kernel: two-level bitmap (1), flat (0), chosen per launch (2)
+  uint32_t short_key32 = 1;      // 1: 32-bit table entries in the short-row numeric kernel where B's columns allow
   uint32_t short_packed = 1;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
@@ -396,7 +397,8 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_sym_big);
   raise_lds_limit(k_sym_hash_wg);
   raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
-  raise_lds_limit(k_num_short<4>); raise_lds_limit(k_num_short<SH_STEPS>);
+  raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
+  raise_lds_limit(k_num_short<4, true>); raise_lds_limit(k_num_short<SH_STEPS, true>);
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -642,6 +644,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "grp_compact") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "grp_compact must be 0, 1 or 2");
     ctx->grp_compact = (uint32_t)value;
+  } else if (n == "short_key32") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_key32 must be 0 or 1");
+    ctx->short_key32 = (uint32_t)value;
   } else if (n == "short_packed") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0 or 1");
     ctx->short_packed = (uint32_t)value;
@@ -1245,7 +1250,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb, gmax);
     } else if (key >= NUM_HASH0 && key < NUM_GLOBAL && (key & 3) == 0) { // short rows
       const uint32_t log2pm = 6 + ((uint32_t)(key - NUM_HASH0) >> 2);
-      const size_t region = ((size_t)32 << log2pm) + SH_SCRATCH;
+      // 32-bit table entries (column << log2pm | product number) when every column fits beside the number
+      const bool k32 = ctx->short_key32 && B->cols <= (1ull << (32 - log2pm)) - 1;
+      const size_t region = num_short_region(log2pm, k32);
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       const uint32_t wpb = pick_wpb(region);
       TRY(ensure_colcdf(ctx, B));
@@ -1253,7 +1260,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
-      hipLaunchKernelGGL(log2pm <= 8 ? k_num_short<4> : k_num_short<SH_STEPS>, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
+      auto kern = k32 ? (log2pm <= 8 ? k_num_short<4, true> : k_num_short<SH_STEPS, true>)
+                      : (log2pm <= 8 ? k_num_short<4, false> : k_num_short<SH_STEPS, false>);
+      hipLaunchKernelGGL(kern, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
                          dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, cm, log2pm, wpb, rpw);
     } else if (key < NUM_GLOBAL) {
       const bool flat = (key & 3) < 3 && ctx->flat_walk;
