@@ -102,6 +102,7 @@ struct spgemm_ctx {
   uint32_t lane_order_adds = 1;  // option: 0 = never rely on it (claim rounds instead)
   uint32_t slice_queues = 1;     // work queues of the slice kernel (8: one per XCD; 1: one for the device)
   uint32_t grp_compact = 2;      // row-group numeric kernel: two-level bitmap (1), flat (0), chosen per launch (2)
+  uint32_t short_sym_spread = 1; // short-row symbolic kernel: log2 of (table slots / 2 / products)
   uint32_t short_key32 = 1;      // 1: 32-bit table entries in the short-row numeric kernel where B's columns allow
   uint32_t short_packed = 1;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
@@ -644,6 +645,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "grp_compact") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "grp_compact must be 0, 1 or 2");
     ctx->grp_compact = (uint32_t)value;
+  } else if (n == "short_sym_spread") {
+    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "short_sym_spread must be 0..2");
+    ctx->short_sym_spread = (uint32_t)value;
   } else if (n == "short_key32") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_key32 must be 0 or 1");
     ctx->short_key32 = (uint32_t)value;
@@ -1073,6 +1077,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t tier = (key - SYM_HASH0) >> 2;
       uint32_t log2s = 7 + tier;
       if ((key & 3) == 0) { // short rows: count only
+        log2s += ctx->short_sym_spread; // a table of 4x the products: probe chains half as long, and the kernel is bound by what it issues
         const size_t region = ((size_t)4 << log2s) + SH_SCRATCH;
         const uint32_t wpb = pick_wpb(region);
         st.rows_hash += cnt;
