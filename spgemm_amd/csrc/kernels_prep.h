@@ -6,12 +6,24 @@
 namespace sg {
 
 // ---- B row info: two uint4 per row, {min col, max col, length, 1 if the row's columns are not strictly
-// increasing} and {start of the row in B.col / B.val (low, high word), 0, 0}: everything the analysis
-// of an A entry needs about its B row sits in one 32-byte record.  info[2 * rows].x counts the rows
-// that are not strictly increasing (zero on entry).  8 lanes per row.
+// increasing} and {start of the row in B.col / B.val (u64), start of its padded records (u64, set by
+// k_prec_patch)}.  The counter of rows that are not strictly increasing is zero on entry.  8 lanes per row.
+// The two 16-byte halves of a row's record, lo = {min col, max col, length, unsorted} and hi =
+// {first entry (u64), first padded record (u64)}: side by side (sh = 1, hi_base = 1: one 32-byte
+// gather serves the analysis of matrices with short rows, which reads both halves per A entry), or
+// in two arrays (sh = 0, hi_base = rows: the analysis of other matrices reads only lo, and twice as
+// many rows then share a cache line).  p[2 * rows].x counts the unsorted rows either way.
+struct RowInfo {
+  uint4 *p;
+  uint32_t sh;
+  uint64_t hi_base;
+  __device__ __forceinline__ uint4 &lo(uint64_t k) const { return p[k << sh]; }
+  __device__ __forceinline__ uint4 &hi(uint64_t k) const { return p[hi_base + (k << sh)]; }
+};
+
 __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
                                                    const uint32_t *__restrict__ b_col,
-                                                   uint4 *__restrict__ info) {
+                                                   RowInfo info) {
   constexpr int G = 8;
   uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   uint32_t lg = threadIdx.x & (G - 1);
@@ -32,9 +44,9 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
   unsorted = group_max<G>(unsorted);
   if (row < rows && lg == 0) {
     uint64_t len = b1 - b0;
-    info[2 * row] = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
-    info[2 * row + 1] = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), 0u, 0u);
-    if (unsorted) atomicAdd(&info[2 * rows].x, 1u);
+    info.lo(row) = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
+    info.hi(row) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), 0u, 0u);
+    if (unsorted) atomicAdd(&info.p[2 * rows].x, 1u);
   }
 }
 
@@ -45,22 +57,22 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
 // short row of A, at most 512 products, cannot refer to them).  The record start of every row goes
 // into the second half of its row-info record.
 constexpr uint32_t PREC_MAX_LEN = 512;
-__global__ void __launch_bounds__(256) k_prec_count(uint64_t rows, const uint4 *__restrict__ info, uint32_t *__restrict__ count) {
+__global__ void __launch_bounds__(256) k_prec_count(uint64_t rows, RowInfo info, uint32_t *__restrict__ count) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  const uint32_t len = info[2 * r].z;
+  const uint32_t len = info.lo(r).z;
   count[r] = len <= PREC_MAX_LEN ? (len + 7u) & ~7u : 0u;
 }
-__global__ void __launch_bounds__(256) k_prec_patch(uint64_t rows, const uint64_t *__restrict__ start, uint4 *__restrict__ info) {
+__global__ void __launch_bounds__(256) k_prec_patch(uint64_t rows, const uint64_t *__restrict__ start, RowInfo info) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  uint4 v = info[2 * r + 1];
+  uint4 v = info.hi(r);
   v.z = (uint32_t)start[r];
   v.w = (uint32_t)(start[r] >> 32);
-  info[2 * r + 1] = v;
+  info.hi(r) = v;
 }
 __global__ void __launch_bounds__(256) k_prec_fill(uint64_t rows, const uint64_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col,
-                                                   const double *__restrict__ b_val, const uint4 *__restrict__ info,
+                                                   const double *__restrict__ b_val, RowInfo info,
                                                    uint4 *__restrict__ prec) {
   constexpr int G = 8;
   const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -68,7 +80,7 @@ __global__ void __launch_bounds__(256) k_prec_fill(uint64_t rows, const uint64_t
   if (row >= rows) return;
   const uint64_t b0 = b_ptr[row], b1 = b_ptr[row + 1];
   if (b1 - b0 > PREC_MAX_LEN) return;
-  const uint4 hi = info[2 * row + 1];
+  const uint4 hi = info.hi(row);
   uint4 *out = prec + (((uint64_t)hi.w << 32) | hi.z);
   for (uint64_t j = b0 + lg; j < b1; j += G) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(b_val[j]);
@@ -115,7 +127,7 @@ __device__ __forceinline__ void analyze_finish(uint32_t row, uint64_t np, uint32
 template <int G>
 __global__ void __launch_bounds__(256)
     k_analyze(uint32_t rows_a, const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
-              const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp, uint32_t long_len) {
+              RowInfo b_info, AnalyzeOut o, ClassParams cp, uint32_t long_len) {
   const uint64_t row64 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const uint32_t row = row64 < rows_a ? (uint32_t)row64 : rows_a; // rows_a: no row (ids beyond 2^32 / G must not alias)
   uint32_t lg = threadIdx.x & (G - 1);
@@ -141,7 +153,7 @@ __global__ void __launch_bounds__(256)
     for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
       uint32_t kcol = a_col[ka];
       if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
-      uint4 bi = b_info[2 * (size_t)kcol];
+      uint4 bi = b_info.lo(kcol);
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);
@@ -161,7 +173,7 @@ __global__ void __launch_bounds__(256)
     if (key >= (uint32_t)SYM_HASH0 && key < (uint32_t)SYM_GLOBAL0 && (key & 3u) == 0u)
       for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
         const size_t k = a_col[ka];
-        const uint4 lo = b_info[2 * k], hi = b_info[2 * k + 1];
+        const uint4 lo = b_info.lo(k), hi = b_info.hi(k);
         o.a_p0[ka] = ((uint64_t)hi.y << 32) | hi.x;
         o.a_len[ka] = lo.z;
         if (o.a_pk) o.a_pk[ka] = ((uint64_t)hi.w << 32) | hi.z;
@@ -193,7 +205,7 @@ __global__ void __launch_bounds__(256)
 // One 256-thread workgroup per long A row.
 __global__ void __launch_bounds__(256)
     k_analyze_long(const uint64_t *__restrict__ a_ptr, const uint32_t *__restrict__ a_col,
-                   const uint4 *__restrict__ b_info, AnalyzeOut o, ClassParams cp) {
+                   RowInfo b_info, AnalyzeOut o, ClassParams cp) {
   __shared__ uint64_t s_np[4];
   __shared__ uint32_t s_mn[4], s_mx[4];
   uint32_t nlong = *o.long_count;
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(256)
     uint64_t np = 0;
     uint32_t mn = 0xFFFFFFFFu, mx = 0;
     for (uint64_t ka = a0 + threadIdx.x; ka < a1; ka += blockDim.x) {
-      uint4 bi = b_info[2 * (size_t)a_col[ka]];
+      uint4 bi = b_info.lo(a_col[ka]);
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);
@@ -276,8 +288,9 @@ __global__ void __launch_bounds__(256)
   // LDS by it (five unknowns per mesh node make groups of five, not of GRP_MAX)
   const uint32_t mn = group_max<64>(wide ? 0u : c), mw = group_max<64>(wide ? c : 0u);
   if ((threadIdx.x & 63u) == 0) {
-    if (mn > gmax_seen[0]) atomicMax(&gmax_seen[0], mn); // the plain read only saves atomics
-    if (mw > gmax_seen[1]) atomicMax(&gmax_seen[1], mw);
+    // the reads only save atomics; they bypass the CU's cache, which would keep showing zero
+    if (mn > __hip_atomic_load(&gmax_seen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[0], mn);
+    if (mw > __hip_atomic_load(&gmax_seen[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[1], mw);
   }
 }
 

@@ -53,6 +53,7 @@ struct spgemm_mat {
   double *d_val = nullptr;
   bool owns = false;
   int device = 0;
+  uint32_t rowinfo_sh = 1;    // layout of d_rowinfo (RowInfo): 1 = halves side by side, 0 = in two arrays
   uint4 *d_rowinfo = nullptr; // {min col, max col, length} per row, built on first use as B
   double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
   uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
@@ -282,15 +283,21 @@ static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uin
   return SPGEMM_OK;
 }
 
+static RowInfo rowinfo_of(const spgemm_mat *B) {
+  return RowInfo{B->d_rowinfo, B->rowinfo_sh, B->rowinfo_sh ? 1ull : B->rows};
+}
+
 static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   if (B->d_rowinfo) return SPGEMM_OK;
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  // short rows of A (which read both halves of a record) need short rows of B
+  mb->rowinfo_sh = B->nnz <= 32 * B->rows ? 1u : 0u;
   TRY(pool_alloc(ctx, (2 * B->rows + 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
   HIP_TRY(hipMemsetAsync(mb->d_rowinfo + 2 * B->rows, 0, sizeof(uint4), ctx->stream)); // count of unsorted rows
   if (B->rows) {
     uint32_t blocks = div_up_u64(B->rows * 8, 256);
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
-                       mb->d_rowinfo);
+                       rowinfo_of(B));
     HIP_TRY(hipGetLastError());
   }
   return SPGEMM_OK;
@@ -306,10 +313,10 @@ static int ensure_prec_layout(spgemm_ctx *ctx, const spgemm_mat *B) {
     TRY(pool_alloc(ctx, b_start + b_part + B->rows * 4, (void **)&mb->d_prow, &mb->bytes_prow));
     uint64_t *partial = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mb->d_prow) + b_start);
     uint32_t *count = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mb->d_prow) + b_start + b_part);
-    hipLaunchKernelGGL(k_prec_count, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, mb->d_rowinfo, count);
+    hipLaunchKernelGGL(k_prec_count, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, rowinfo_of(B), count);
     TRY(launch_scan(ctx, count, B->rows, mb->d_prow, partial));
     hipLaunchKernelGGL(k_prec_patch, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, mb->d_prow,
-                       mb->d_rowinfo);
+                       rowinfo_of(B));
     HIP_TRY(hipGetLastError());
   }
   return SPGEMM_OK;
@@ -322,7 +329,7 @@ static int ensure_prec(spgemm_ctx *ctx, const spgemm_mat *B) {
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
   TRY(pool_alloc(ctx, (B->nnz + 7 * std::min<uint64_t>(B->rows, B->nnz)) * sizeof(uint4), (void **)&mb->d_prec, &mb->bytes_prec));
   hipLaunchKernelGGL(k_prec_fill, dim3(div_up_u64(B->rows * 8, 256)), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
-                     B->d_val, B->d_rowinfo, mb->d_prec);
+                     B->d_val, rowinfo_of(B), mb->d_prec);
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -1022,10 +1029,10 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
 
   AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same, a_p0, a_len, a_pk};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
-                     A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
+                     A->d_ptr, A->d_col, rowinfo_of(B), ao, ctx->cp, ctx->long_len);
   if (max_long > 1 || A->nnz > ctx->long_len)
     hipLaunchKernelGGL(k_analyze_long, dim3(std::min<uint32_t>(max_long, 1024)), dim3(256), 0, ctx->stream, A->d_ptr,
-                       A->d_col, B->d_rowinfo, ao, ctx->cp);
+                       A->d_col, rowinfo_of(B), ao, ctx->cp);
   hipLaunchKernelGGL(k_group, dim3(div_up_u64(rows, 256)), dim3(256), 0, ctx->stream, rows, A->d_ptr, r_same, r_key, r_ub,
                      r_gcnt, r_lead, ctx->row_groups, long_count + 1);
   HIP_TRY(hipGetLastError());
@@ -1609,8 +1616,8 @@ extern "C" int spgemm_row_nprod(spgemm_ctx *ctx, const spgemm_mat *A, const spge
   uint8_t *same = ar.take<uint8_t>(rows);
   AnalyzeOut ao{c0, c1, ub, key, np, total, long_rows, long_count, same, nullptr, nullptr};
   hipLaunchKernelGGL(k_analyze<16>, dim3(div_up_u64((uint64_t)rows * 16, 256)), dim3(256), 0, ctx->stream, rows,
-                     A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp, ctx->long_len);
-  hipLaunchKernelGGL(k_analyze_long, dim3(256), dim3(256), 0, ctx->stream, A->d_ptr, A->d_col, B->d_rowinfo, ao, ctx->cp);
+                     A->d_ptr, A->d_col, rowinfo_of(B), ao, ctx->cp, ctx->long_len);
+  hipLaunchKernelGGL(k_analyze_long, dim3(256), dim3(256), 0, ctx->stream, A->d_ptr, A->d_col, rowinfo_of(B), ao, ctx->cp);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(row_nprod_out, np, (size_t)rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
