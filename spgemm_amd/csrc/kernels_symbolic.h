@@ -168,11 +168,16 @@ __global__ void __launch_bounds__(256)
 // The same algorithm as k_sym_hash with the four wavefronts of a workgroup sharing one table (the
 // pattern of a row does not depend on the order in which its products are seen): a table of 8192
 // slots takes 64 KiB of LDS, and one wavefront per table would leave two wavefronts on a CU.
-// The wavefronts take the A entries round robin.  LDS: keys[S] | cnt[S/2] | tk[S/2] = 8*S bytes.
+// The wavefronts take the A entries round robin, except those whose B row has more than
+// HWG_LONG entries: these (up to HWG_LONG_CAP of them) are put aside and then walked by all four
+// wavefronts together - such rows have a few A entries with hub rows of B among them, and the
+// wavefront that drew the hub kept the other three waiting for half of the kernel's time.
+// LDS: keys[S] | cnt[S/2] | tk[S/2] = 8*S bytes.
+constexpr uint32_t HWG_LONG = 256, HWG_LONG_CAP = 64;
 __global__ void __launch_bounds__(256)
     k_sym_hash_wg(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_n, s_wsum[4];
+  __shared__ uint32_t s_n, s_wsum[4], s_nlong, s_longk[HWG_LONG_CAP];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
@@ -182,23 +187,39 @@ __global__ void __launch_bounds__(256)
   const uint32_t row = scalar_view(rows)[xcd_remap(blockIdx.x, gridDim.x)];
   for (uint32_t i = tid; i < S; i += 256) keys[i] = EMPTY_KEY;
   for (uint32_t i = tid; i < NB; i += 256) cnt[i] = 0u;
-  if (tid == 0) s_n = 0u;
+  if (tid == 0) { s_n = 0u; s_nlong = 0u; }
   __syncthreads();
   const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
   uint32_t mine = 0;
+  auto insert = [&](uint32_t c) {
+    uint32_t h = hash_slot(c, log2s);
+    for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
+      const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+      if (old == EMPTY_KEY) { ++mine; break; }
+      if (old == c) break;
+      h = (h + 1u) & mask;
+    }
+  };
   for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
     const uint32_t k = scalar_view(A.col)[ka];
     const uint64_t b0 = scalar_view(B.ptr)[k], b1 = scalar_view(B.ptr)[k + 1];
-    for (uint64_t j = b0 + lane; j < b1; j += 64) {
-      const uint32_t c = B.col[j];
-      uint32_t h = hash_slot(c, log2s);
-      for (uint32_t it = 0; it < S; ++it) { // bounded: the table is at most half full
-        const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
-        if (old == EMPTY_KEY) { ++mine; break; }
-        if (old == c) break;
-        h = (h + 1u) & mask;
+    if (b1 - b0 > HWG_LONG) { // wave-uniform
+      uint32_t slot = 0;
+      if (lane == 0) slot = atomicAdd(&s_nlong, 1u);
+      slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+      if (slot < HWG_LONG_CAP) {
+        if (lane == 0) s_longk[slot] = k;
+        continue; // taken by all wavefronts below
       }
     }
+    for (uint64_t j = b0 + lane; j < b1; j += 64) insert(B.col[j]);
+  }
+  __syncthreads();
+  const uint32_t nlong = min(s_nlong, HWG_LONG_CAP);
+  for (uint32_t i = 0; i < nlong; ++i) {
+    const uint32_t k = s_longk[i];
+    const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+    for (uint64_t j = b0 + tid; j < b1; j += 256) insert(B.col[j]);
   }
   mine = group_last<64>(group_incl_scan<64>(mine));
   if (lane == 0 && mine) atomicAdd(&s_n, mine);
