@@ -174,10 +174,12 @@ __global__ void __launch_bounds__(256)
 // wavefront that drew the hub kept the other three waiting for half of the kernel's time.
 // LDS: keys[S] | cnt[S/2] | tk[S/2] = 8*S bytes.
 constexpr uint32_t HWG_LONG = 256, HWG_LONG_CAP = 64;
-__global__ void __launch_bounds__(256)
+// THREADS: 256, or 512 for the largest table (two workgroups of it fit a CU: 16 instead of 8 wavefronts)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
     k_sym_hash_wg(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_n, s_wsum[4], s_nlong, s_longk[HWG_LONG_CAP];
+  __shared__ uint32_t s_n, s_wsum[THREADS / 64], s_nlong, s_longk[HWG_LONG_CAP];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const uint32_t S = 1u << log2s, NB = S >> 1, mask = S - 1u;
@@ -185,8 +187,8 @@ __global__ void __launch_bounds__(256)
   uint32_t *cnt = keys + S;
   uint32_t *tk = cnt + NB;
   const uint32_t row = scalar_view(rows)[xcd_remap(blockIdx.x, gridDim.x)];
-  for (uint32_t i = tid; i < S; i += 256) keys[i] = EMPTY_KEY;
-  for (uint32_t i = tid; i < NB; i += 256) cnt[i] = 0u;
+  for (uint32_t i = tid; i < S; i += THREADS) keys[i] = EMPTY_KEY;
+  for (uint32_t i = tid; i < NB; i += THREADS) cnt[i] = 0u;
   if (tid == 0) { s_n = 0u; s_nlong = 0u; }
   __syncthreads();
   const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(256)
       h = (h + 1u) & mask;
     }
   };
-  for (uint64_t ka = a0 + w; ka < a1; ka += 4) {
+  for (uint64_t ka = a0 + w; ka < a1; ka += THREADS / 64) {
     const uint32_t k = scalar_view(A.col)[ka];
     const uint64_t b0 = scalar_view(B.ptr)[k], b1 = scalar_view(B.ptr)[k + 1];
     if (b1 - b0 > HWG_LONG) { // wave-uniform
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = 0; i < nlong; ++i) {
     const uint32_t k = s_longk[i];
     const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-    for (uint64_t j = b0 + tid; j < b1; j += 256) insert(B.col[j]);
+    for (uint64_t j = b0 + tid; j < b1; j += THREADS) insert(B.col[j]);
   }
   mine = group_last<64>(group_incl_scan<64>(mine));
   if (lane == 0 && mine) atomicAdd(&s_n, mine);
@@ -228,13 +230,13 @@ __global__ void __launch_bounds__(256)
   const uint32_t cmin = m.cmin[row];
   const float scale = (float)NB / (float)(m.cmax[row] - cmin + 1u);
   // pass A: bucket counts (buckets are monotone in the column)
-  for (uint32_t s = tid; s < S; s += 256) {
+  for (uint32_t s = tid; s < S; s += THREADS) {
     const uint32_t key = keys[s];
     if (key != EMPTY_KEY) atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u);
   }
   __syncthreads();
-  // exclusive scan of cnt: NB / 256 consecutive buckets per thread (NB is a multiple of 256 here)
-  const uint32_t per = NB >> 8;
+  // exclusive scan of cnt: NB / THREADS consecutive buckets per thread (NB is a multiple of THREADS here)
+  const uint32_t per = NB / THREADS;
   uint32_t local = 0;
   for (uint32_t i = 0; i < per; ++i) local += cnt[tid * per + i];
   const uint32_t incl = group_incl_scan<64>(local);
@@ -249,14 +251,14 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   // pass B: scatter into bucket order; afterwards cnt[b] = end of bucket b
-  for (uint32_t s = tid; s < S; s += 256) {
+  for (uint32_t s = tid; s < S; s += THREADS) {
     const uint32_t key = keys[s];
     if (key != EMPTY_KEY) tk[atomicAdd(&cnt[min(NB - 1u, (uint32_t)((float)(key - cmin) * scale))], 1u)] = key;
   }
   __syncthreads();
   // pass C: rank inside the bucket, write sorted
   uint32_t *out = m.temp_cols + m.t_off[row];
-  for (uint32_t p = tid; p < n; p += 256) {
+  for (uint32_t p = tid; p < n; p += THREADS) {
     const uint32_t key = tk[p];
     const uint32_t b = min(NB - 1u, (uint32_t)((float)(key - cmin) * scale));
     const uint32_t start = b ? cnt[b - 1] : 0u, end = cnt[b];

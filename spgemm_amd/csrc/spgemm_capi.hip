@@ -403,7 +403,7 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
   raise_lds_limit(k_sym_big);
-  raise_lds_limit(k_sym_hash_wg);
+  raise_lds_limit(k_sym_hash_wg<256>); raise_lds_limit(k_sym_hash_wg<512>);
   raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
   raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
   raise_lds_limit(k_num_short<4, true>); raise_lds_limit(k_num_short<SH_STEPS, true>);
@@ -1102,9 +1102,13 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t wpb = pick_wpb(region);
       st.rows_hash += cnt;
       if (!flat && log2s >= 12) { // 32 KiB of table and more: the four wavefronts of a workgroup share it
-        TRY(prof_begin(ctx, 0, 1, 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
-        hipLaunchKernelGGL(k_sym_hash_wg, dim3(cnt), dim3(256), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB, rm,
-                           log2s);
+        TRY(prof_begin(ctx, 0, 1, log2s >= 13 ? 512 : 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
+        if (log2s >= 13)
+          hipLaunchKernelGGL(k_sym_hash_wg<512>, dim3(cnt), dim3(512), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB,
+                             rm, log2s);
+        else
+          hipLaunchKernelGGL(k_sym_hash_wg<256>, dim3(cnt), dim3(256), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB,
+                             rm, log2s);
         HIP_TRY(hipGetLastError());
         TRY(prof_end(ctx));
         continue;
