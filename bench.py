@@ -287,11 +287,21 @@ def main():
                     help="use the distributed operator even at N = 1 (rehearsal of the N > 1 path)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus == 1 and world == 1 and not args.dist:
-        run_single(args)
-    else:
-        from spgemm_amd import dist
-        dist.bench_main(args)
+    # Standard output carries the one JSON line and nothing else: libraries that write to file
+    # descriptor 1 (RCCL prints a version banner when its first communicator is made) are sent to
+    # standard error for the length of the run.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = json_out
+    try:
+        if args.gpus == 1 and world == 1 and not args.dist:
+            run_single(args)
+        else:
+            from spgemm_amd import dist
+            dist.bench_main(args)
+    finally:
+        json_out.flush()
 
 
 if __name__ == "__main__":
