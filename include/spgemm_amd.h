@@ -129,6 +129,12 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   profile_launches                                0 off, 1 HIP events per launch, 2 + per-launch sums */
 int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value);
 
+/* What spgemm_create found out about the context's device (no counterpart in the reference).
+ *   "lane_order_probe"   1 when one LDS fp64 add applied lanes that share an address in ascending lane
+ *                        order in every trial of the probe (the flat walks then add with one instruction)
+ *   "cu_count"           compute units of the device */
+int spgemm_device_property(const spgemm_ctx *ctx, const char *name, int64_t *value);
+
 /* ---- matrices: replace matrix::ManagedCSRMatrix / CSRMatrix
  *      (include/matrix_impl.hpp:230-384) --------------------------------------------------- */
 /* Copy a host CSR to the device. The caller keeps ownership of the host arrays. */

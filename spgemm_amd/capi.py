@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SPGEMM_AMD_LIB") or os.path.join(_HERE, "libspgemm_am
 # every symbol include/spgemm_amd.h declares
 EXPORTED_SYMBOLS = [
     "spgemm_version", "spgemm_last_error", "spgemm_device_count",
-    "spgemm_create", "spgemm_destroy", "spgemm_ctx_device", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option",
+    "spgemm_create", "spgemm_destroy", "spgemm_ctx_device", "spgemm_set_stream", "spgemm_synchronize", "spgemm_set_option", "spgemm_device_property",
     "spgemm_mat_from_host", "spgemm_mat_wrap_device", "spgemm_mat_invalidate", "spgemm_mat_info", "spgemm_mat_device_ptrs",
     "spgemm_mat_to_host", "spgemm_mat_rows_to_host", "spgemm_mat_check", "spgemm_mat_free",
     "spgemm_multiply", "spgemm_symbolic", "spgemm_numeric", "spgemm_get_stats", "spgemm_get_launches",
@@ -96,6 +96,7 @@ def load() -> ctypes.CDLL:
         "spgemm_set_stream": (i32, [vp, vp]),
         "spgemm_synchronize": (i32, [vp]),
         "spgemm_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
+        "spgemm_device_property": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
         "spgemm_mat_from_host": (i32, [vp, u64, u64, u64, vp, vp, vp, pp]),
         "spgemm_mat_wrap_device": (i32, [vp, u64, u64, u64, vp, vp, vp, i32, pp]),
         "spgemm_mat_invalidate": (i32, [vp, vp]),
@@ -263,6 +264,12 @@ class Context:
 
     def set_option(self, name: str, value: int):
         _check(load().spgemm_set_option(self.handle, name.encode(), int(value)))
+
+    def device_property(self, name: str) -> int:
+        """What spgemm_create found out about the device ("lane_order_probe", "cu_count")."""
+        v = ctypes.c_int64(0)
+        _check(load().spgemm_device_property(self.handle, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def set_stream(self, hip_stream: Optional[int]):
         """Run on the caller's hipStream_t, given as an integer handle (torch:

@@ -600,6 +600,15 @@ extern "C" int spgemm_synchronize(spgemm_ctx *ctx) {
   return SPGEMM_OK;
 }
 
+extern "C" int spgemm_device_property(const spgemm_ctx *ctx, const char *name, int64_t *value) {
+  if (!ctx || !name || !value) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  const std::string n(name);
+  if (n == "lane_order_probe") *value = ctx->hw_lane_order ? 1 : 0;
+  else if (n == "cu_count") *value = ctx->cu_count;
+  else return fail(SPGEMM_ERR_INVALID, "unknown device property %s", name);
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return fail(SPGEMM_ERR_INVALID, "ctx or name is NULL");
   std::string n(name);

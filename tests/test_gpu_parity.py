@@ -367,3 +367,46 @@ def test_wrapped_b_refilled_in_place_needs_invalidate(ctx):
     orc.assert_same(run(), orc.spgemm(to_ocsr(M1), to_ocsr(M2)), rtol=0.0)
     dB.free()
     dA.free()
+
+
+def test_lane_order_probe_and_both_add_modes():
+    """The device passes the probe of spgemm_create (one LDS fp64 add applies lanes that share an
+    address in lane order), and the flat-walk kernels give the oracle's bits with the
+    single-instruction adds and with claim rounds alike.  The matrix makes many products of one
+    step hit the same output: every row of A refers to rows of B that all hold the same few
+    columns, with values of very different magnitude, so that any other order of the additions
+    rounds differently."""
+    rng = np.random.default_rng(77)
+    n, k = 600, 400
+    r = np.repeat(np.arange(n), 40)
+    c = rng.integers(0, k, len(r))
+    v = np.ldexp(1.0 + rng.random(len(r)), rng.integers(-30, 31, len(r))) * rng.choice([-1.0, 1.0], len(r))
+    A = hostcsr.HostCsr.from_coo(n, k, r, c, v, sum_duplicates=True).sorted_rows()
+    hot = np.array([3, 17, 18, 250, 251, 252, 399])  # the same few columns in every row of B
+    rb = np.repeat(np.arange(k), len(hot))
+    cb = np.tile(hot, k)
+    vb = np.ldexp(1.0 + rng.random(len(rb)), rng.integers(-30, 31, len(rb)))
+    B = hostcsr.HostCsr.from_coo(k, k, rb, cb, vb, sum_duplicates=True).sorted_rows()
+    E = orc.spgemm(to_ocsr(A), to_ocsr(B))
+    seen = []
+    for mode in (1, 0):
+        for hash_path in (0, 1):
+            c2 = capi.Context(0)
+            try:
+                assert c2.device_property("cu_count") > 0
+                seen.append(c2.device_property("lane_order_probe"))
+                c2.set_option("lane_order_adds", mode)
+                c2.set_option("row_groups", 0)
+                c2.set_option("short_max_nprod", 0)
+                if hash_path:
+                    c2.set_option("window_max_span", 0)
+                dA = c2.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+                dB = c2.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
+                dC = c2.multiply(dA, dB)
+                rp, ci, vv = dC.to_host()
+                orc.assert_same(orc.OCsr(A.rows, B.cols, rp, ci, vv), E, rtol=0.0)
+            finally:
+                c2.close()
+    if not all(s == 1 for s in seen):  # not an error: the kernels then take the claim rounds, checked above
+        import warnings
+        warnings.warn("this device does not apply the lanes of one LDS fp64 add in lane order")
