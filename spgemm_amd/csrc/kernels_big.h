@@ -283,6 +283,10 @@ constexpr uint32_t SLICE_P4 = SLICE_W % 1024u == 0 && SLICE_W / 1024u <= 3u ? 10
 static_assert(SLICE_W % 64u == 0 && SLICE_W % SLICE_P4 == 0 && SLICE_W / SLICE_P4 <= 3u, "unsupported SLICE_W");
 // LDS of one workgroup: cols u32 | vals f64 | owner u32 (claim rounds only) | flat-walk scratch
 __host__ __device__ constexpr uint32_t slice_lds(bool hw_order) { return SLICE_W * (hw_order ? 12u : 16u) + FLAT_BYTES; }
+#ifndef SG_SLICE_LONG_MIN
+#define SG_SLICE_LONG_MIN 16
+#endif
+constexpr uint32_t SLICE_LONG_MIN = SG_SLICE_LONG_MIN; // mean expected piece length from which a block takes its pieces one B row at a time
 #ifndef SG_SLICE_PF
 #define SG_SLICE_PF 3
 #endif
@@ -579,7 +583,7 @@ __global__ void __launch_bounds__(64)
         // expected length of a piece: what is left of the B row, spread over the chunks that follow
         const uint32_t est = act ? (uint32_t)min(end - cur, (uint64_t)SLICE_W) / chunks_left : 0u;
         SG_STAMP(3)
-        if (group_sum<64>(est) >= 16u * nact) {
+        if (group_sum<64>(est) >= SLICE_LONG_MIN * nact) {
           // long pieces: one B row at a time, its entries over the lanes (distinct columns: no
           // conflicts); U pieces are loaded and searched together, then added in A order
           // group = UG pieces; the loads of the next group fly while this one is searched and added
