@@ -138,6 +138,22 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- small results for the host: up to six runs of 32-bit words copied into the context's pinned host
+// buffer by ONE launch (a copy call per counter costs about 10 us each on the stream) -----------------
+struct ReportSeg {
+  const uint32_t *src;
+  uint32_t *dst;
+  uint32_t words;
+};
+struct ReportSegs {
+  ReportSeg s[6];
+};
+__global__ void __launch_bounds__(256) k_report(ReportSegs r) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    for (uint32_t w = threadIdx.x; w < r.s[i].words; w += 256) r.s[i].dst[w] = r.s[i].src[w];
+}
+
 // ---- probe: order of the lanes of one LDS fp64 add that share an address -----------------------------
 // The flat walks add up to 64 products with ONE ds_add_f64 instruction and need the lanes that hit
 // the same accumulator to be applied in ascending lane order (the CPU's order of the products).

@@ -115,6 +115,7 @@ struct spgemm_ctx {
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
+  void *d_pinned = nullptr; // the same buffer as the device addresses it (k_report writes results into it)
   uint32_t *d_small = nullptr; // 4 KiB of device words for flags and small results
   unsigned char *noalloc_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress)
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
@@ -451,6 +452,7 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
   for (auto &ev : ctx->ev)
     if (e == hipSuccess) { what = "hipEventCreate"; e = hipEventCreate(&ev); }
   if (e == hipSuccess) { what = "hipHostMalloc"; e = hipHostMalloc(&ctx->h_pinned, PINNED_BYTES); }
+  if (e == hipSuccess) { what = "hipHostGetDevicePointer"; e = hipHostGetDevicePointer(&ctx->d_pinned, ctx->h_pinned, 0); }
   if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc((void **)&ctx->d_small, 4096); }
   // address of this device's copy of the allocation-free entry point's scratch array
   if (e == hipSuccess) { what = "hipGetSymbolAddress"; e = hipGetSymbolAddress((void **)&ctx->noalloc_scratch, HIP_SYMBOL(scratch)); }
@@ -943,6 +945,25 @@ static int prof_collect(spgemm_ctx *ctx, const spgemm_mat *A, const uint32_t *r_
   return SPGEMM_OK;
 }
 
+// Queues ONE launch that copies the given runs of device words to their places in the pinned host
+// buffer (`host_field` is an address inside ctx->h_pinned); the host reads them after its next
+// synchronisation of the stream.
+struct Report {
+  ReportSegs segs{};
+  int n = 0;
+  void add(const spgemm_ctx *ctx, void *host_field, const void *dev_src, size_t bytes) {
+    const size_t off = reinterpret_cast<char *>(host_field) - reinterpret_cast<char *>(ctx->h_pinned);
+    segs.s[n++] = ReportSeg{reinterpret_cast<const uint32_t *>(dev_src),
+                            reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->d_pinned) + off), (uint32_t)(bytes / 4)};
+  }
+  int launch(spgemm_ctx *ctx) {
+    for (int i = n; i < 6; ++i) segs.s[i] = ReportSeg{nullptr, nullptr, 0};
+    hipLaunchKernelGGL(k_report, dim3(1), dim3(256), 0, ctx->stream, segs);
+    HIP_TRY(hipGetLastError());
+    return SPGEMM_OK;
+  }
+};
+
 // ---- the multiply -------------------------------------------------------------------------------
 struct HostCounts {
   uint64_t bin_off[MAX_BINS + 1];
@@ -1050,11 +1071,15 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   TRY(launch_partition(ctx, r_key, rows, SYM_NBINS, ps, perm, bin_off));
 
   HostCounts *hc = reinterpret_cast<HostCounts *>(ctx->h_pinned);
-  HIP_TRY(hipMemcpyAsync(hc->bin_off, bin_off, (SYM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(&hc->total_a, t_off + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(hc->nprod_parts, total_nprod, NPROD_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(&hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(hc->gmax_seen, long_count + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  {
+    Report rep;
+    rep.add(ctx, hc->bin_off, bin_off, (SYM_NBINS + 1) * 8);
+    rep.add(ctx, &hc->total_a, t_off + rows, 8);
+    rep.add(ctx, hc->nprod_parts, total_nprod, NPROD_SLOTS * 8);
+    rep.add(ctx, &hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 4);
+    rep.add(ctx, hc->gmax_seen, long_count + 1, 8);
+    TRY(rep.launch(ctx));
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const bool b_sorted = hc->b_unsorted == 0;
   const uint32_t gmax_narrow = std::min<uint32_t>(std::max<uint32_t>(hc->gmax_seen[0], 1), GRP_MAX);
@@ -1196,7 +1221,8 @@ static int numeric_prepare(spgemm_ctx *ctx, const spgemm_mat *A, const uint64_t 
   hc->max_len_big = 0;
   memset(hc->bin_off, 0, sizeof(hc->bin_off));
   if (rows == 0) return SPGEMM_OK;
-  HIP_TRY(hipMemcpyAsync(&hc->total_a, d_row_ptr + rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+  Report rep;
+  rep.add(ctx, &hc->total_a, d_row_ptr + rows, 8);
   PartScratch ps{pl.pblocks, pl.blk_hist, pl.blk_off, pl.partial};
   TRY(launch_partition(ctx, pl.r_numkey, rows, NUM_NBINS, ps, pl.perm, pl.bin_off));
   HIP_TRY(hipMemsetAsync(pl.zero_count, 0, (32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE) * 8, ctx->stream));
@@ -1206,9 +1232,10 @@ static int numeric_prepare(spgemm_ctx *ctx, const spgemm_mat *A, const uint64_t 
     hipLaunchKernelGGL(k_slice_maxlen, dim3(std::min<uint32_t>(div_up_u64(rows, 256), 2048)), dim3(256), 0, ctx->stream,
                        rows, A->d_ptr, pl.r_numkey, max_len_big);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&hc->max_len_big, max_len_big, 4, hipMemcpyDeviceToHost, ctx->stream));
+    rep.add(ctx, &hc->max_len_big, max_len_big, 4);
   }
-  HIP_TRY(hipMemcpyAsync(hc->bin_off, pl.bin_off, (NUM_NBINS + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  rep.add(ctx, hc->bin_off, pl.bin_off, (NUM_NBINS + 1) * 8);
+  TRY(rep.launch(ctx));
   return SPGEMM_OK;
 }
 static uint64_t numeric_counts_ready(spgemm_ctx *ctx) { // after the stream has been synchronised
@@ -1376,8 +1403,12 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   }
   HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
   TRY(prof_collect(ctx, A, pl.r_nnz, 1));
-  HIP_TRY(hipMemcpyAsync(&hc->total_a, zero_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(&hc->total_nprod, zero_count + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+  {
+    Report rep;
+    rep.add(ctx, &hc->total_a, zero_count, 8);
+    rep.add(ctx, &hc->total_nprod, zero_count + 3, 8);
+    TRY(rep.launch(ctx));
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (hc->total_nprod) return fail(SPGEMM_ERR_STATE, "internal: the big-row numeric kernel met a damaged work list");
 #ifdef SG_SLICE_STAMPS
