@@ -1020,7 +1020,10 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   const bool short_aux = ctx->cp.short_max_nprod > 0;
   // padded records of B's rows: only where short rows are likely at all (mean products per row of A
   // within twice the short-row limit); without them the short-row kernel reads B's own arrays
-  const double mean_prod = (double)A->nnz / (double)std::max<uint64_t>(A->rows, 1) * (double)B->nnz / (double)std::max<uint64_t>(B->rows, 1);
+  // (a B that holds only the sections a rank needs has empty rows: its mean row length is taken to
+  // be at least A's)
+  const double mean_a = (double)A->nnz / (double)std::max<uint64_t>(A->rows, 1);
+  const double mean_prod = mean_a * std::max(mean_a, (double)B->nnz / (double)std::max<uint64_t>(B->rows, 1));
   const bool short_pk = short_aux && ctx->short_packed && (B->d_prow || mean_prod <= 2.0 * ctx->cp.short_max_nprod);
   if (short_pk) TRY(ensure_prec_layout(ctx, B));
   if (short_aux) need += align_up(A->nnz * 8, 256) + align_up(A->nnz * 4, 256); // short rows: B row start and length per A entry

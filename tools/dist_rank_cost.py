@@ -2,7 +2,7 @@
 the operator gets the first 1/P of the rows of A and the whole B (it then moves only the sections
 its bitmap marks)."""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 import numpy as np
 from spgemm_amd import hostcsr, dist as sd

@@ -1,6 +1,6 @@
 """Host-timed pieces of one distributed step at world size 1 for the first 1/P of the shell rows."""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 import numpy as np
 from spgemm_amd import hostcsr, dist as sd
