@@ -357,12 +357,25 @@ __global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *partial, uint32_t
 
 // out[i] = exclusive prefix; out[n] = total.  Items are laid out thread-contiguous here so the
 // per-thread prefix is a running sum.
+// own_spine: `partial` holds the workgroups' raw totals (k_scan_spine has not run) and every
+// workgroup adds up those before it on its own - one launch less for the short scans that are
+// most of them; the sums of all workgroups together read nparts^2 / 2 values, so the host takes this
+// form only up to SCAN_OWN_SPINE_MAX parts.
+constexpr uint32_t SCAN_OWN_SPINE_MAX = 4096;
 __global__ void __launch_bounds__(SCAN_BLOCK)
     k_scan_final(const uint32_t *__restrict__ in, uint64_t n, const uint64_t *__restrict__ partial,
-                 uint64_t *__restrict__ out, uint32_t nparts) {
+                 uint64_t *__restrict__ out, uint32_t nparts, uint32_t own_spine) {
   __shared__ uint64_t s_wave[4];
   __shared__ uint32_t s_items[SCAN_BLOCK * SCAN_ITEMS];
   uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+  uint64_t before = 0; // sum of the items of the workgroups before this one
+  if (own_spine) {
+    uint64_t mine = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += SCAN_BLOCK) mine += partial[j];
+    block_excl_scan64(mine, s_wave, &before);
+  } else {
+    before = partial[blockIdx.x];
+  }
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     uint32_t l = i * SCAN_BLOCK + threadIdx.x;
@@ -377,14 +390,19 @@ __global__ void __launch_bounds__(SCAN_BLOCK)
     v[i] = s_items[threadIdx.x * SCAN_ITEMS + i];
     s += v[i];
   }
-  uint64_t ex = block_excl_scan64(s, s_wave, nullptr) + partial[blockIdx.x];
+  uint64_t tot;
+  uint64_t ex = block_excl_scan64(s, s_wave, &tot) + before;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     uint64_t idx = base + (uint64_t)threadIdx.x * SCAN_ITEMS + i;
     if (idx < n) out[idx] = ex;
     ex += v[i];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nparts];
+  if (own_spine) {
+    if (blockIdx.x == nparts - 1u && threadIdx.x == 0) out[n] = before + tot;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[n] = partial[nparts];
+  }
 }
 
 // ---- stable partition of rows by an 8-bit key ---------------------------------------------------

@@ -255,8 +255,9 @@ static uint32_t scan_parts(uint64_t n) { return div_up_u64(n ? n : 1, (uint64_t)
 static int launch_scan(spgemm_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *partial) {
   uint32_t nparts = scan_parts(n);
   hipLaunchKernelGGL(k_scan_partials, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial);
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, ctx->stream, partial, nparts);
-  hipLaunchKernelGGL(k_scan_final, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial, out, nparts);
+  const uint32_t own_spine = nparts <= SCAN_OWN_SPINE_MAX ? 1u : 0u;
+  if (!own_spine) hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, ctx->stream, partial, nparts);
+  hipLaunchKernelGGL(k_scan_final, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial, out, nparts, own_spine);
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
