@@ -109,14 +109,18 @@ __global__ void __launch_bounds__(256)
 //   two population counts.  dielFilterV3real-like rows: 8 instead of 5 wavefronts per CU, 13.6 ms
 //   instead of 20.0; af_shell10-like rows (hull of 16,384 columns, kernel bound by instruction
 //   issue): 3.6 ms instead of 3.2, so the host picks the form per launch (grp_use_compact).
+// The A values of the group's rows stay in registers, entry t of a row in lane t % 64 (the walk
+// takes one A entry at a time, wave-uniformly, so a v_readlane hands the value to the scalar unit;
+// staged in LDS they cost a read per row and B entry and 2.5 KiB per wavefront).
 // LDS per wavefront: bitmap (flat: bmp[words]; compact: top[grp_top_words(words)] | cw[cap]) |
-// vals[gmax][cap] | avals[gmax][alen], with (gmax, alen) = (GRP_MAX, GRP_ALEN) for TIER 0,
-// (GRP_MAX_WIDE, GRP_ALEN_MID) for TIER 1 and (GRP_MAX_WIDE, GRP_ALEN_WIDE) for TIER 2.
+// vals[gmax][cap]; the A rows have at most GRP_ALEN entries for TIER 0, GRP_ALEN_MID for TIER 1 and
+// GRP_ALEN_WIDE for TIER 2.
 __host__ __device__ inline uint32_t grp_top_words(uint32_t words) { return (words + 31u) / 32u; }
 // gmax: rows a group of the launch has at most (from the analysis, <= GRP_MAX / GRP_MAX_WIDE)
 __host__ __device__ inline size_t grp_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
   const size_t bitmap = compact ? (size_t)grp_top_words(words) * 8u + (size_t)cap * 8u : (size_t)words * 8u;
-  return bitmap + (size_t)gmax * cap * 8u + (size_t)gmax * alen * 8u;
+  (void)alen;
+  return bitmap + (size_t)gmax * cap * 8u;
 }
 // the two-level form where the flat bitmap would be more than a third of the wavefront's LDS
 __host__ __device__ inline bool grp_use_compact(uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(256)
   uint64_t *cw = top + topw; // compact: {outputs in the word (bits), outputs before} of the words with outputs; flat: of all words
   uint32_t *cw32 = reinterpret_cast<uint32_t *>(cw);
   double *vals = reinterpret_cast<double *>(cw + (COMPACT ? cap : words));
-  double *avals = vals + (size_t)gmax * cap;
+  constexpr uint32_t gmaxc = TIER ? GRP_MAX_WIDE : GRP_MAX; // rows a group of this tier can have
   // row state through the scalar unit (all of it was written by earlier kernels)
   const uint32_t row = scalar_view(rows)[idx];
   const uint32_t cnt = min((uint32_t)scalar_view(m.gcnt)[row], gmax);
@@ -164,12 +168,17 @@ __global__ void __launch_bounds__(256)
   } else {
     for (uint32_t i = lane; i < nw; i += 64) cw[i] = 0ull;
   }
+  double av_lo[gmaxc], av_hi[gmaxc]; // A values of row j: entries lane and 64 + lane
 #pragma unroll
-  for (uint32_t j = 0; j < GRP_MAX; ++j) {
+  for (uint32_t j = 0; j < gmaxc; ++j) {
+    av_lo[j] = 0.0;
+    av_hi[j] = 0.0;
     if (j < cnt) {
       for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
       const double *av = A.val + readlane64(my_a, j);
-      for (uint32_t t = lane; t < len_a && t < alen; t += 64) avals[j * alen + t] = av[t];
+      if (lane < len_a) av_lo[j] = av[lane];
+      if constexpr (alen > 64)
+        if (64u + lane < len_a) av_hi[j] = av[64u + lane];
     }
   }
   lds_fence();
@@ -219,7 +228,15 @@ __global__ void __launch_bounds__(256)
     const uint32_t cc = c - base;
     const uint64_t e = cw[compact_word(cc >> 5)];
     const uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
-    for (uint32_t j = 0; j < cnt; ++j) lds_add_f64(&vals[j * cap + pos], __dmul_rn(avals[j * alen + apos], bv));
+    const uint32_t ap = (uint32_t)__builtin_amdgcn_readfirstlane((int)apos); // the A entry: the same for every lane
+#pragma unroll
+    for (uint32_t j = 0; j < gmaxc; ++j)
+      if (j < cnt) { // wave-uniform
+        double a;
+        if constexpr (alen > 64) a = ap < 64u ? readlane_f64(av_lo[j], ap) : readlane_f64(av_hi[j], ap - 64u);
+        else a = readlane_f64(av_lo[j], ap);
+        lds_add_f64(&vals[j * cap + pos], __dmul_rn(a, bv));
+      }
   });
   lds_fence();
   uint32_t nz = 0;
