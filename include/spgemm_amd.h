@@ -95,6 +95,8 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   short-row kernels (count-only symbolic pass, numeric
  *                                                   pass that sorts the row's products itself); 0: none
  *   short_rpw                                       rows one wavefront of those kernels pipelines
+ *   analyze_lanes                                   lanes per row of A in the analysis: 8, 16, 32, or
+ *                                                   0 (default) = by the mean row length
  *   short_key32                                     1 (default): 32-bit entries in the sorting table
  *                                                   of that kernel when B has few enough columns
  *   grp_compact                                     row-group numeric kernel: 1 two-level bitmap over
