@@ -605,7 +605,6 @@ def bench_main(args):
     A, name = bench_mod.make_workload(args)
     op = DistSpgemm(A, None, impl=args.impl, n_sections=512, seed=1, device_index=local,
                     partition=getattr(args, "partition", "naive"), stages=getattr(args, "stages", 1))
-    op.ctx.set_option("profile_launches", 1)  # HIP events around every launch, on the operator's stream
     for o in getattr(args, "opt", []):
         opt_name, opt_value = o.split("=")
         op.ctx.set_option(opt_name, int(opt_value))
@@ -614,20 +613,25 @@ def bench_main(args):
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    per_launch_ms = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         op.gemm()
-        ms = np.array([l["ms"] for l in op.ctx.launches()])
-        per_launch_ms = ms if per_launch_ms is None or len(ms) != len(per_launch_ms) else per_launch_ms + ms
     op.ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     st = op.last_stats
-    # one untimed step that also sums the rows of every launch (bytes per launch); rank 0 reports the
-    # roofline figure of ITS dominant numeric launch against one GPU's HBM peak
+    # The timed steps above carry no instrumentation (HIP events around each of the ~50 launches of a
+    # step and the host round trip that reads them are a tenth of a 1-ms step).  The roofline figure of
+    # rank 0's dominant numeric launch comes from the same number of steps run again with events on
+    # the operator's stream, then one more step that also sums the rows of every launch (bytes).
+    op.ctx.set_option("profile_launches", 1)
+    per_launch_ms = None
+    for _ in range(args.steps):
+        op.gemm()
+        ms = np.array([l["ms"] for l in op.ctx.launches()])
+        per_launch_ms = ms if per_launch_ms is None or len(ms) != len(per_launch_ms) else per_launch_ms + ms
     op.ctx.set_option("profile_launches", 2)
     op.gemm()
     roofline = None
@@ -644,7 +648,7 @@ def bench_main(args):
             roofline = {"bound": "hbm", "achieved": achieved, "peak": bench_mod.HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / bench_mod.HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                         "kernel_ms": dom["ms"], "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b,
-                        "scope": "rank 0's launch, one GPU's peak"}
+                        "scope": "rank 0's launch, one GPU's peak; HIP events over the same number of steps, repeated after the timed region"}
     t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     t = _all_reduce(t, op=dist.ReduceOp.MAX)
     sums = torch.tensor([st["nprod"], st["nnz_c"], st["nnz_a"], st["nnz_b"], op.bytes_sent_per_run,
