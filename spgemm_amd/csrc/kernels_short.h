@@ -9,8 +9,11 @@ namespace sg {
 // A row takes this path when it has at most SH_MAX_NPROD products and at most SH_MAX_ALEN entries
 // in its A row (the whole A row then sits in one wavefront, one entry per lane).
 constexpr int SH_STEPS = SH_MAX_NPROD / 64; // steps of 64 products a row can take
-// per-wavefront walk scratch: st[64] u32 | p0s[64] u64 | avs[2][64] f64 | marks[SH_MAX_NPROD] u8
-constexpr uint32_t SH_SCRATCH = 256 + 512 + 1024 + SH_MAX_NPROD;
+// per-wavefront walk scratch: st[64] u32 | p0s[64] u64 | marks[64 * steps] u8 | avs[64] f64 (numeric only);
+// steps: steps of 64 products the rows of the launch can take
+__host__ __device__ constexpr uint32_t sh_scratch(bool numeric, uint32_t steps) {
+  return 256u + 512u + 64u * steps + (numeric ? 512u : 0u);
+}
 
 // Monotone map of the columns of B onto [0, nnz(B)]: F(c) = number of entries of B in columns < c,
 // piecewise linear over CDF_BINS equal column ranges (cdf[b] = entries in the bins before b, exact
@@ -82,8 +85,8 @@ __device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const Ro
 // marks, and a running max over the lanes (and over the steps) gives every product its entry: no
 // search.  The loads of the B entries are issued here and consumed by stage C of the same row, one
 // row later in program order.
-// LDS scratch per wavefront: st[64] u32 | p0s[64] u64 | avs[2][64] f64 | marks[SH_MAX_NPROD] u8; the
-// A values are kept for stage C in the half of avs that `parity` names.
+// LDS scratch per wavefront: sh_scratch(NUMERIC, STEPS) bytes; the A values stay in avs for stage C,
+// which reads them before the next row is expanded.
 // STEPS: steps of 64 products the rows of the launch can take.
 template <bool NUMERIC, int STEPS> struct ShortSet {
   uint32_t c[STEPS], t[STEPS];
@@ -94,11 +97,12 @@ template <bool NUMERIC, int STEPS> struct ShortSet {
 };
 template <bool NUMERIC, int STEPS>
 __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, const ShortFetch &f, uint32_t lane,
-                                             unsigned char *scratch, uint32_t parity, ShortSet<NUMERIC, STEPS> &s) {
+                                             unsigned char *scratch, ShortSet<NUMERIC, STEPS> &s) {
+  static_assert(STEPS == 4 || STEPS == 8, "marks are cleared with one 4- or 8-byte store per lane");
   uint32_t *st = reinterpret_cast<uint32_t *>(scratch);
   uint64_t *p0s = reinterpret_cast<uint64_t *>(scratch + 256);
-  double *avs = reinterpret_cast<double *>(scratch + 768) + 64u * parity;
-  uint8_t *marks = scratch + 1792;
+  uint8_t *marks = scratch + 768;
+  double *avs = reinterpret_cast<double *>(scratch + 768 + 64 * STEPS);
   s.row = f.row;
   if constexpr (NUMERIC) {
     s.n = f.n; s.off = f.off; s.cmin = f.cmin; s.cmax = f.cmax;
@@ -106,14 +110,15 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
     s.f[0] = cm.cdf[b0]; s.f[1] = cm.cdf[b0 + 1]; s.f[2] = cm.cdf[b1]; s.f[3] = cm.cdf[b1 + 1];
   }
   lds_fence(); // the scratch of the row before has been read
-  reinterpret_cast<uint64_t *>(marks)[lane] = 0ull; // SH_MAX_NPROD = 64 * 8 bytes
+  if constexpr (STEPS == 8) reinterpret_cast<uint64_t *>(marks)[lane] = 0ull; // 64 * STEPS bytes
+  else reinterpret_cast<uint32_t *>(marks)[lane] = 0u;
   const uint32_t incl = group_incl_scan<64>(f.len);
   s.total = min(group_last<64>(incl), (uint32_t)STEPS * 64u);
   lds_fence();
   st[lane] = incl - f.len;
   p0s[lane] = f.p0;
   if constexpr (NUMERIC) avs[lane] = f.av;
-  if (f.len && incl - f.len < SH_MAX_NPROD) marks[incl - f.len] = (uint8_t)(lane + 1u);
+  if (f.len && incl - f.len < 64u * STEPS) marks[incl - f.len] = (uint8_t)(lane + 1u);
   lds_fence();
   uint32_t carry = 1u;
   const uint32_t nsteps = (s.total + 63u) >> 6;
@@ -162,18 +167,18 @@ __global__ void __launch_bounds__(256)
   if (w >= wpb || first64 >= nrows) return;
   const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
   const uint32_t S = 1u << log2s, mask = S - 1u;
-  const size_t region = (size_t)S * 4u + SH_SCRATCH;
+  const size_t region = (size_t)S * 4u + sh_scratch(false, STEPS);
   uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
   unsigned char *scratch = smem + w * region + (size_t)S * 4u;
   const ColMap none{nullptr, 0, 0.0};
   ShortFetch fa;
   ShortSet<false, STEPS> cur, nxt;
   short_fetch<false>(A, B, m, nullptr, rows, first, lane, fa);
-  short_expand<false, STEPS>(B, none, fa, lane, scratch, 0u, cur);
+  short_expand<false, STEPS>(B, none, fa, lane, scratch, cur);
   if (first + 1u < last) short_fetch<false>(A, B, m, nullptr, rows, first + 1u, lane, fa);
   for (uint32_t i = first; i < last; ++i) {
     if (i + 1u < last) {
-      short_expand<false, STEPS>(B, none, fa, lane, scratch, 0u, nxt);
+      short_expand<false, STEPS>(B, none, fa, lane, scratch, nxt);
       if (i + 2u < last) short_fetch<false>(A, B, m, nullptr, rows, i + 2u, lane, fa);
     }
     for (uint32_t j = lane * 4u; j < S; j += 256u)
@@ -222,13 +227,16 @@ __global__ void __launch_bounds__(256)
 //    row's products sorted by column and, inside a column, in the order the CPU adds them.  No
 //    wrap-around: at most `products` entries lie past the last home slot.  The product's value goes
 //    to prodv[q].
-// 2. The table is read in slot order.  The first entry of a column sums the column's entries one
-//    after the other (they are adjacent) - the CPU's order of additions, bit for bit - and is written
-//    at the position given by the number of column starts before it.
+// 2. The occupied slots are moved to the front of the table, keeping their order.  The first entry
+//    of a column sums the column's entries one after the other (they are adjacent) - the CPU's
+//    order of additions, bit for bit - and is written at the position given by the number of column
+//    starts before it.
 // K32: the table entry is 32 bits, column << log2pm | product number, for a B with fewer than
 // 2^(32 - log2pm) columns: half the table, 32-bit atomics and compares.
+// rows of up to 256 products go to the kernel with 4 steps, longer ones to the one with SH_STEPS
+__host__ __device__ inline uint32_t num_short_steps(uint32_t log2pm) { return log2pm <= 8 ? 4u : (uint32_t)SH_STEPS; }
 __host__ __device__ inline size_t num_short_region(uint32_t log2pm, bool k32) {
-  return ((size_t)(k32 ? 20u : 32u) << log2pm) + SH_SCRATCH;
+  return ((size_t)(k32 ? 20u : 32u) << log2pm) + sh_scratch(true, num_short_steps(log2pm));
 }
 template <int STEPS, bool K32>
 __global__ void __launch_bounds__(256)
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
   const uint32_t PM = 1u << log2pm;
   const uint32_t cshift = K32 ? log2pm : 32u; // an entry is column << cshift | product number
-  const size_t region = num_short_region(log2pm, K32);
+  const size_t region = ((size_t)(K32 ? 20u : 32u) << log2pm) + sh_scratch(true, STEPS);
   unsigned char *reg = smem + w * region;
   key_t *tab = reinterpret_cast<key_t *>(reg);
   double *prodv = reinterpret_cast<double *>(reg + (size_t)PM * 3u * sizeof(key_t));
@@ -254,15 +262,11 @@ __global__ void __launch_bounds__(256)
   uint32_t nz = 0;
   ShortFetch fa;
   ShortSet<true, STEPS> cur, nxt;
-  const double *avs = reinterpret_cast<const double *>(scratch + 768);
+  const double *avs = reinterpret_cast<const double *>(scratch + 768 + 64 * STEPS);
   short_fetch<true>(A, B, m, o.c_ptr, rows, first, lane, fa);
-  short_expand<true, STEPS>(B, cm, fa, lane, scratch, first & 1u, cur);
+  short_expand<true, STEPS>(B, cm, fa, lane, scratch, cur);
   if (first + 1u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, first + 1u, lane, fa);
   for (uint32_t i = first; i < last; ++i) {
-    if (i + 1u < last) {
-      short_expand<true, STEPS>(B, cm, fa, lane, scratch, (i + 1u) & 1u, nxt);
-      if (i + 2u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, i + 2u, lane, fa);
-    }
     const uint32_t total = min(cur.total, PM), n = cur.n;
     const uint64_t off = cur.off;
     const uint32_t H = 2u * total, T = (3u * total + 63u) & ~63u; // slots in use: a multiple of 64, <= 3 PM
@@ -290,10 +294,16 @@ __global__ void __launch_bounds__(256)
       h[u] = 0;
       if (cur.c[u] != EMPTY_KEY) {
         const uint32_t q = (uint32_t)u * 64u + lane;
-        prodv[q] = __dmul_rn(avs[64u * (i & 1u) + cur.t[u]], cur.bv[u]);
+        prodv[q] = __dmul_rn(avs[cur.t[u]], cur.bv[u]);
         x[u] = ((key_t)cur.c[u] << cshift) | q;
         h[u] = min(H - 1u, (uint32_t)((fc[u] - f_lo) * scale));
       }
+    }
+    // the row's values and A entries are used up: the next row is expanded now (its B entries are in
+    // flight during the rest of this row, and only half as many registers are live across the loads)
+    if (i + 1u < last) {
+      short_expand<true, STEPS>(B, cm, fa, lane, scratch, nxt);
+      if (i + 2u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, i + 2u, lane, fa);
     }
     // 1. sorted insertion; the chains of a lane's products advance together
     for (;;) {
@@ -311,27 +321,52 @@ __global__ void __launch_bounds__(256)
       if (!__any(open)) break;
     }
     lds_fence();
-    // 2. runs of equal columns, in slot order
+    // 2. the occupied slots are moved to the front of the table, in slot order (16 bytes of slots per
+    //    lane and step; an entry moves to a slot at or before its own, and every lane has read its
+    //    slots before any lane writes: in place)
+    {
+      constexpr uint32_t SPL = 16u / sizeof(key_t); // slots per lane
+      uint32_t base = 0;
+      for (uint32_t s0 = 0; s0 < T; s0 += 64u * SPL) {
+        const uint32_t sl = s0 + lane * SPL;
+        key_t e[SPL];
+        if constexpr (K32) {
+          const uint4 v = sl < T ? *reinterpret_cast<const uint4 *>(&tab[sl]) : make_uint4(~0u, ~0u, ~0u, ~0u);
+          e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+        } else {
+          const ulonglong2 v = sl < T ? *reinterpret_cast<const ulonglong2 *>(&tab[sl]) : make_ulonglong2(~0ull, ~0ull);
+          e[0] = v.x; e[1] = v.y;
+        }
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SPL; ++k) c += e[k] != EMPTY64 ? 1u : 0u;
+        const uint32_t incl = group_incl_scan<64>(c);
+        uint32_t p = base + incl - c;
+        base += group_last<64>(incl);
+        lds_fence();
+#pragma unroll
+        for (uint32_t k = 0; k < SPL; ++k)
+          if (e[k] != EMPTY64) tab[p++] = e[k];
+      }
+    }
+    lds_fence();
+    // 3. runs of equal columns: the first entry of a column sums the column's entries, which follow it
     uint32_t base = 0;
     const bool plain = n == total; // no column twice: every entry is its own output
-    for (uint32_t s0 = 0; s0 < T; s0 += 64u) {
+    for (uint32_t s0 = 0; s0 < total; s0 += 64u) {
       const uint32_t sl = s0 + lane;
-      const key_t e = tab[sl];
+      const bool occ = sl < total;
+      const key_t e = occ ? tab[sl] : EMPTY64;
       const uint32_t col = col_of(e);
-      const bool occ = e != EMPTY64;
-      // a column starts where the slot before holds another column or nothing (an empty slot reads as
-      // column 0xFFFFFFFF, which no entry has)
-      // (an empty slot reads as the largest column there is under either width, which no entry has:
-      // with 32-bit entries B has fewer than 2^(32 - log2pm) columns)
-      const uint32_t prev_col = (sl && !plain) ? col_of(tab[sl - 1u]) : col_of(EMPTY64);
-      const bool start = occ && prev_col != col;
+      const uint32_t prev_col = (sl && !plain && occ) ? col_of(tab[sl - 1u]) : col_of(EMPTY64);
+      const bool start = occ && prev_col != col; // (no entry has the column an empty key reads as)
       const uint64_t bal = __ballot(start);
       if (start) {
         double v = prodv[q_of(e)];
         if (!plain)
-          for (uint32_t j = sl + 1u; j < T; ++j) {
+          for (uint32_t j = sl + 1u; j < total; ++j) {
             const key_t g = tab[j];
-            if (col_of(g) != col || g == EMPTY64) break;
+            if (col_of(g) != col) break;
             v += prodv[q_of(g)];
           }
         const uint32_t pp = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));

@@ -1138,7 +1138,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t log2s = 7 + tier;
       if ((key & 3) == 0) { // short rows: count only
         log2s += ctx->short_sym_spread; // a table of 4x the products: probe chains half as long, and the kernel is bound by what it issues
-        const size_t region = ((size_t)4 << log2s) + SH_SCRATCH;
+        const size_t region = ((size_t)4 << log2s) + sh_scratch(false, tier <= 2 ? 4u : (uint32_t)SH_STEPS);
         const uint32_t wpb = pick_wpb(region);
         st.rows_hash += cnt;
         TRY(prof_begin(ctx, 0, 1, 1, cnt, log2s, 0, region * wpb, rows_bin));
@@ -1331,8 +1331,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
-      auto kern = k32 ? (log2pm <= 8 ? k_num_short<4, true> : k_num_short<SH_STEPS, true>)
-                      : (log2pm <= 8 ? k_num_short<4, false> : k_num_short<SH_STEPS, false>);
+      const bool four = num_short_steps(log2pm) == 4;
+      auto kern = k32 ? (four ? k_num_short<4, true> : k_num_short<SH_STEPS, true>)
+                      : (four ? k_num_short<4, false> : k_num_short<SH_STEPS, false>);
       hipLaunchKernelGGL(kern, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
                          dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, cm, log2pm, wpb, rpw);
     } else if (key < NUM_GLOBAL) {
