@@ -102,10 +102,13 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   grp_compact                                     row-group numeric kernel: 1 two-level bitmap over
  *                                                   the column hull (less LDS), 0 flat bitmap (fewer
  *                                                   instructions), 2 (default) chosen per launch
- *   short_packed                                    1 (default): the numeric one reads the rows of B
- *                                                   as 16-byte {column, value} records padded to
- *                                                   128-byte lines (built once per B handle, at most
- *                                                   7 records of padding per row); 0: from B's arrays
+ *   short_packed                                    1: the numeric one reads the rows of B as 16-byte
+ *                                                   {column, value} records padded to 128-byte lines
+ *                                                   (built once per B handle, at most 7 records of
+ *                                                   padding per row); 2 (default): and the symbolic one
+ *                                                   their columns from a padded array of its own (rows
+ *                                                   start at multiples of 32 bytes); 0: both read B's
+ *                                                   arrays
  *   g_thresh0, g_thresh1, g_thresh2                 mean B-row length classes; <= g_thresh2: flat walk
  *   flat_walk, row_groups, big_rows                 0/1 switches of the flat walk, of the grouping of
  *                                                   identical A rows, of the big-row kernels (B sorted)

@@ -55,7 +55,10 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
 // at a multiple of 128 bytes: such a row is fetched as len / 8 whole 128-byte lines, where its
 // 4-byte columns and 8-byte values in two arrays straddle three to four.  Longer rows get none (a
 // short row of A, at most 512 products, cannot refer to them).  The record start of every row goes
-// into the second half of its row-info record.
+// into the second half of its row-info record.  The columns alone are kept a second time at the
+// same positions (a row starts at a multiple of 32 bytes; where all rows have 9 to 16 entries, of 64):
+// the count-only symbolic pass fetches such a row as one line, where B's own column array straddles
+// two half of the time.
 constexpr uint32_t PREC_MAX_LEN = 512;
 __global__ void __launch_bounds__(256) k_prec_count(uint64_t rows, RowInfo info, uint32_t *__restrict__ count) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(256) k_prec_patch(uint64_t rows, const uint64_
 }
 __global__ void __launch_bounds__(256) k_prec_fill(uint64_t rows, const uint64_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col,
                                                    const double *__restrict__ b_val, RowInfo info,
-                                                   uint4 *__restrict__ prec) {
+                                                   uint4 *__restrict__ prec, uint32_t *__restrict__ pcol) {
   constexpr int G = 8;
   const uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const uint32_t lg = threadIdx.x & (G - 1);
@@ -81,10 +84,14 @@ __global__ void __launch_bounds__(256) k_prec_fill(uint64_t rows, const uint64_t
   const uint64_t b0 = b_ptr[row], b1 = b_ptr[row + 1];
   if (b1 - b0 > PREC_MAX_LEN) return;
   const uint4 hi = info.hi(row);
-  uint4 *out = prec + (((uint64_t)hi.w << 32) | hi.z);
+  const uint64_t start = ((uint64_t)hi.w << 32) | hi.z;
+  uint4 *out = prec + start;
+  uint32_t *out_col = pcol + start; // the columns alone, at the same positions: rows start at multiples of 32 bytes
   for (uint64_t j = b0 + lg; j < b1; j += G) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(b_val[j]);
-    out[j - b0] = make_uint4(b_col[j], 0u, (uint32_t)v, (uint32_t)(v >> 32));
+    const uint32_t c = b_col[j];
+    out[j - b0] = make_uint4(c, 0u, (uint32_t)v, (uint32_t)(v >> 32));
+    out_col[j - b0] = c;
   }
 }
 
@@ -102,8 +109,8 @@ struct AnalyzeOut {
   uint32_t *long_rows;     // rows with more than long_len A entries (handled by k_analyze_long)
   uint32_t *long_count;
   uint8_t *r_same;         // 1 when the row's column list equals the previous row's (same order)
-  uint64_t *a_p0;          // per A entry of a short row (kernels_short.h): start of its B row ...
-  uint32_t *a_len;         // ... and the B row's length (both may be null: no short rows)
+  uint64_t *a_p0;          // per A entry of a short row (kernels_short.h): start of its B row (may be null) ...
+  uint32_t *a_len;         // ... and the B row's length (null: no short rows)
   uint64_t *a_pk;          // ... and the start of the B row's padded records (may be null)
 };
 
@@ -141,6 +148,9 @@ __global__ void __launch_bounds__(256)
     is_long = (a1 - a0) > long_len;
   }
   uint32_t differs = 1;
+  // a row of at most G entries (one per lane) keeps the records it reads for the per-entry arrays below
+  const bool one_pass = o.a_len && (a1 - a0) <= (uint64_t)G;
+  uint4 keep_lo = make_uint4(0u, 0u, 0u, 0u), keep_hi = keep_lo;
   if (!is_long) {
     // does the row repeat the previous row's column list?
     uint64_t p0 = 0;
@@ -154,6 +164,10 @@ __global__ void __launch_bounds__(256)
       uint32_t kcol = a_col[ka];
       if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
       uint4 bi = b_info.lo(kcol);
+      if (one_pass) {
+        keep_lo = bi;
+        keep_hi = b_info.hi(kcol); // (the other half of the record: the same line)
+      }
       if (bi.z) {
         np += bi.z;
         mn = min(mn, bi.x);
@@ -167,17 +181,27 @@ __global__ void __launch_bounds__(256)
   mx = group_max<G>(mx);
   // a short row leaves, per A entry, the start and length of the B row for its two kernels (the
   // records were just read: these loads hit the caches)
-  if (row < rows_a && !is_long && o.a_p0) {
+  if (row < rows_a && !is_long && o.a_len) {
     const uint32_t len_a = (uint32_t)(a1 - a0);
     const uint32_t key = sym_key_of(np, np ? (mx - mn + 1u) : 0u, len_a, cp);
-    if (key >= (uint32_t)SYM_HASH0 && key < (uint32_t)SYM_GLOBAL0 && (key & 3u) == 0u)
-      for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
-        const size_t k = a_col[ka];
-        const uint4 lo = b_info.lo(k), hi = b_info.hi(k);
-        o.a_p0[ka] = ((uint64_t)hi.y << 32) | hi.x;
-        o.a_len[ka] = lo.z;
-        if (o.a_pk) o.a_pk[ka] = ((uint64_t)hi.w << 32) | hi.z;
+    if (key >= (uint32_t)SYM_HASH0 && key < (uint32_t)SYM_GLOBAL0 && (key & 3u) == 0u) {
+      if (one_pass) {
+        const uint64_t ka = a0 + lg;
+        if (ka < a1) {
+          if (o.a_p0) o.a_p0[ka] = ((uint64_t)keep_hi.y << 32) | keep_hi.x;
+          o.a_len[ka] = keep_lo.z;
+          if (o.a_pk) o.a_pk[ka] = ((uint64_t)keep_hi.w << 32) | keep_hi.z;
+        }
+      } else {
+        for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
+          const size_t k = a_col[ka];
+          const uint4 lo = b_info.lo(k), hi = b_info.hi(k);
+          if (o.a_p0) o.a_p0[ka] = ((uint64_t)hi.y << 32) | hi.x;
+          o.a_len[ka] = lo.z;
+          if (o.a_pk) o.a_pk[ka] = ((uint64_t)hi.w << 32) | hi.z;
+        }
       }
+    }
   }
   uint64_t contrib = 0;
   if (row < rows_a && lg == 0) {

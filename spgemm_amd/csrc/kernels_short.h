@@ -25,6 +25,7 @@ struct ColMap {
   uint32_t shift;                 // bin of column c = c >> shift
   double inv_width;               // 2^-shift
   const uint4 *__restrict__ prec; // B rows as padded {column, 0, value} records (k_prec_fill), or null
+  const uint32_t *__restrict__ pcol; // the columns of those records alone, at the same positions, or null
 };
 __device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
   const uint32_t b = c >> cm.shift;
@@ -52,13 +53,14 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
 //
 // Stage A (ShortFetch): lane t holds A entry t of the row: its value, start and length of B row k.
 struct ShortFetch {
-  uint32_t row, len, n, cmin, cmax;
+  uint32_t row, len, alen, n, cmin, cmax; // len: of the lane's B row; alen: of the A row
   uint64_t p0, off;
   double av;
 };
 template <bool NUMERIC>
-__device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const RowMeta &m, const uint64_t *c_ptr,
-                                            const uint32_t *rows, uint32_t idx, uint32_t lane, ShortFetch &f) {
+__device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const RowMeta &m, const ColMap &cm,
+                                            const uint64_t *c_ptr, const uint32_t *rows, uint32_t idx, uint32_t lane,
+                                            ShortFetch &f) {
   f.row = scalar_view(rows)[idx];
   const uint64_t a0 = scalar_view(A.ptr)[f.row], a1 = scalar_view(A.ptr)[f.row + 1];
   if constexpr (NUMERIC) {
@@ -68,12 +70,13 @@ __device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const Ro
     f.cmax = scalar_view(m.cmax)[f.row];
   }
   const uint64_t ka = a0 + lane;
+  f.alen = (uint32_t)(a1 - a0);
   f.len = 0;
   f.p0 = 0;
   f.av = 0.0;
   if (ka < a1) { // start and length of the B row: left per A entry by the analysis, read in a stream
-    if constexpr (NUMERIC) f.p0 = m.a_pk ? m.a_pk[ka] : m.a_p0[ka]; // wave-uniform choice
-    else f.p0 = m.a_p0[ka];
+    if constexpr (NUMERIC) f.p0 = cm.prec ? m.a_pk[ka] : m.a_p0[ka]; // wave-uniform choices
+    else f.p0 = cm.pcol ? m.a_pk[ka] : m.a_p0[ka];
     f.len = m.a_len[ka];
     if constexpr (NUMERIC) f.av = A.val[ka];
   }
@@ -83,7 +86,11 @@ __device__ __forceinline__ void short_fetch(const Csr &A, const Csr &B, const Ro
 // row order) in lane q % 64 of step q / 64.  The exclusive prefix sums of the B row lengths go to
 // LDS and a byte array marks, at each entry's first product, the entry (t + 1); a step reads its 64
 // marks, and a running max over the lanes (and over the steps) gives every product its entry: no
-// search.  The loads of the B entries are issued here and consumed by stage C of the same row, one
+// search.  Where the B rows are all short (up to 4, 8 or 16 entries) and the A row has few enough
+// entries, every A entry gets a slot of 4, 8 or 16 lanes instead (product number = entry * slot +
+// position, still in the CPU loop's order, with gaps): no prefix sums, marks or running max.
+// qmax: product numbers the caller can take (a power of two).
+// The loads of the B entries are issued here and consumed by stage C of the same row, one
 // row later in program order.
 // LDS scratch per wavefront: sh_scratch(NUMERIC, STEPS) bytes; the A values stay in avs for stage C,
 // which reads them before the next row is expanded.
@@ -97,7 +104,7 @@ template <bool NUMERIC, int STEPS> struct ShortSet {
 };
 template <bool NUMERIC, int STEPS>
 __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, const ShortFetch &f, uint32_t lane,
-                                             unsigned char *scratch, ShortSet<NUMERIC, STEPS> &s) {
+                                             unsigned char *scratch, uint32_t qmax, ShortSet<NUMERIC, STEPS> &s) {
   static_assert(STEPS == 4 || STEPS == 8, "marks are cleared with one 4- or 8-byte store per lane");
   uint32_t *st = reinterpret_cast<uint32_t *>(scratch);
   uint64_t *p0s = reinterpret_cast<uint64_t *>(scratch + 256);
@@ -110,18 +117,27 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
     s.f[0] = cm.cdf[b0]; s.f[1] = cm.cdf[b0 + 1]; s.f[2] = cm.cdf[b1]; s.f[3] = cm.cdf[b1 + 1];
   }
   lds_fence(); // the scratch of the row before has been read
-  if constexpr (STEPS == 8) reinterpret_cast<uint64_t *>(marks)[lane] = 0ull; // 64 * STEPS bytes
-  else reinterpret_cast<uint32_t *>(marks)[lane] = 0u;
   const uint32_t incl = group_incl_scan<64>(f.len);
   s.total = min(group_last<64>(incl), (uint32_t)STEPS * 64u);
-  lds_fence();
-  st[lane] = incl - f.len;
+  // slot per A entry: 1 << sh lanes, when every B row fits and the numbers stay below qmax
+  const uint32_t sh = __any(f.len > 8u) ? 4u : __any(f.len > 4u) ? 3u : 2u;
+  const bool slots = !__any(f.len > 16u) && (f.alen << sh) <= min(qmax, 64u * (uint32_t)STEPS);
+  uint32_t nsteps;
+  if (slots) {
+    st[lane] = f.len;
+    nsteps = ((f.alen << sh) + 63u) >> 6;
+  } else {
+    if constexpr (STEPS == 8) reinterpret_cast<uint64_t *>(marks)[lane] = 0ull; // 64 * STEPS bytes
+    else reinterpret_cast<uint32_t *>(marks)[lane] = 0u;
+    lds_fence();
+    st[lane] = incl - f.len;
+    if (f.len && incl - f.len < 64u * STEPS) marks[incl - f.len] = (uint8_t)(lane + 1u);
+    nsteps = (s.total + 63u) >> 6;
+  }
   p0s[lane] = f.p0;
   if constexpr (NUMERIC) avs[lane] = f.av;
-  if (f.len && incl - f.len < 64u * STEPS) marks[incl - f.len] = (uint8_t)(lane + 1u);
   lds_fence();
   uint32_t carry = 1u;
-  const uint32_t nsteps = (s.total + 63u) >> 6;
 #pragma unroll
   for (int u = 0; u < STEPS; ++u) {
     s.c[u] = EMPTY_KEY;
@@ -129,12 +145,22 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
     s.t[u] = 0;
     if ((uint32_t)u < nsteps) { // wave-uniform
       const uint32_t q = (uint32_t)u * 64u + lane;
-      const bool valid = q < s.total;
-      const uint32_t mk = valid ? (uint32_t)marks[q] : 0u;
-      const uint32_t tt = max(wave_incl_max(mk), carry);
-      carry = (uint32_t)__builtin_amdgcn_readlane((int)tt, 63);
-      const uint32_t t = tt - 1u;
-      const uint64_t p = p0s[t] + (q - st[t]);
+      bool valid;
+      uint32_t t;
+      uint64_t p;
+      if (slots) { // wave-uniform
+        t = q >> sh;
+        const uint32_t j = q & ((1u << sh) - 1u);
+        valid = j < st[t]; // (t < 64; the lanes past the A row hold length 0)
+        p = p0s[t] + j;
+      } else {
+        valid = q < s.total;
+        const uint32_t mk = valid ? (uint32_t)marks[q] : 0u;
+        const uint32_t tt = max(wave_incl_max(mk), carry);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)tt, 63);
+        t = tt - 1u;
+        p = p0s[t] + (q - st[t]);
+      }
       s.t[u] = t;
       if constexpr (NUMERIC) {
         if (cm.prec) { // the B rows as padded records: one 16-byte load, len / 8 lines per row
@@ -148,7 +174,7 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
           s.bv[u] = B.val[p];
         }
       } else {
-        if (valid) s.c[u] = B.col[p];
+        if (valid) s.c[u] = (cm.pcol ? cm.pcol : B.col)[p];
       }
     }
   }
@@ -159,7 +185,7 @@ __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, con
 template <int STEPS>
 __global__ void __launch_bounds__(256)
     k_sym_count(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t log2s,
-                uint32_t wpb, uint32_t rpw) {
+                uint32_t wpb, uint32_t rpw, const uint32_t *__restrict__ pcol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,38 +196,41 @@ __global__ void __launch_bounds__(256)
   const size_t region = (size_t)S * 4u + sh_scratch(false, STEPS);
   uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
   unsigned char *scratch = smem + w * region + (size_t)S * 4u;
-  const ColMap none{nullptr, 0, 0.0};
+  const ColMap none{nullptr, 0, 0.0, nullptr, pcol};
   ShortFetch fa;
   ShortSet<false, STEPS> cur, nxt;
-  short_fetch<false>(A, B, m, nullptr, rows, first, lane, fa);
-  short_expand<false, STEPS>(B, none, fa, lane, scratch, cur);
-  if (first + 1u < last) short_fetch<false>(A, B, m, nullptr, rows, first + 1u, lane, fa);
+  short_fetch<false>(A, B, m, none, nullptr, rows, first, lane, fa);
+  short_expand<false, STEPS>(B, none, fa, lane, scratch, 64u * STEPS, cur);
+  if (first + 1u < last) short_fetch<false>(A, B, m, none, nullptr, rows, first + 1u, lane, fa);
   for (uint32_t i = first; i < last; ++i) {
     if (i + 1u < last) {
-      short_expand<false, STEPS>(B, none, fa, lane, scratch, nxt);
-      if (i + 2u < last) short_fetch<false>(A, B, m, nullptr, rows, i + 2u, lane, fa);
+      short_expand<false, STEPS>(B, none, fa, lane, scratch, 64u * STEPS, nxt);
+      if (i + 2u < last) short_fetch<false>(A, B, m, none, nullptr, rows, i + 2u, lane, fa);
     }
     for (uint32_t j = lane * 4u; j < S; j += 256u)
       *reinterpret_cast<uint4 *>(&keys[j]) = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
     lds_fence();
-    // the probe chains of a lane's products advance together
+    // The probe chains of a lane's products advance together: the compare-and-swaps of a round are
+    // issued back to back and their results read afterwards, without a branch in between (a lane
+    // that is done swaps "empty" for "empty", which changes no slot; it starts from a slot of its
+    // own so that the idle lanes do not meet on one address).
     uint32_t mine = 0, h[STEPS], c[STEPS];
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
       c[u] = cur.c[u];
-      h[u] = hash_slot(c[u], log2s);
+      h[u] = c[u] != EMPTY_KEY ? hash_slot(c[u], log2s) : lane;
     }
     for (;;) {
+      uint32_t old[STEPS];
+#pragma unroll
+      for (int u = 0; u < STEPS; ++u) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, c[u]);
       bool open = false;
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
-        if (c[u] != EMPTY_KEY) {
-          const uint32_t old = atomicCAS(&keys[h[u]], EMPTY_KEY, c[u]);
-          if (old == EMPTY_KEY) { ++mine; c[u] = EMPTY_KEY; }
-          else if (old == c[u]) c[u] = EMPTY_KEY;
-          else h[u] = (h[u] + 1u) & mask; // the table is at most half full: an empty slot comes
-          open |= c[u] != EMPTY_KEY;
-        }
+        mine += (old[u] == EMPTY_KEY && c[u] != EMPTY_KEY) ? 1u : 0u;
+        c[u] = (old[u] == EMPTY_KEY || old[u] == c[u]) ? EMPTY_KEY : c[u];
+        h[u] = (h[u] + 1u) & mask; // the table is at most half full: an empty slot comes
+        open |= c[u] != EMPTY_KEY;
       }
       if (!__any(open)) break;
     }
@@ -263,9 +292,9 @@ __global__ void __launch_bounds__(256)
   ShortFetch fa;
   ShortSet<true, STEPS> cur, nxt;
   const double *avs = reinterpret_cast<const double *>(scratch + 768 + 64 * STEPS);
-  short_fetch<true>(A, B, m, o.c_ptr, rows, first, lane, fa);
-  short_expand<true, STEPS>(B, cm, fa, lane, scratch, cur);
-  if (first + 1u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, first + 1u, lane, fa);
+  short_fetch<true>(A, B, m, cm, o.c_ptr, rows, first, lane, fa);
+  short_expand<true, STEPS>(B, cm, fa, lane, scratch, PM, cur);
+  if (first + 1u < last) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, first + 1u, lane, fa);
   for (uint32_t i = first; i < last; ++i) {
     const uint32_t total = min(cur.total, PM), n = cur.n;
     const uint64_t off = cur.off;
@@ -291,7 +320,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
       x[u] = EMPTY64;
-      h[u] = 0;
+      h[u] = lane; // (a lane without a product takes part with "empty", which changes no slot: a slot of its own)
       if (cur.c[u] != EMPTY_KEY) {
         const uint32_t q = (uint32_t)u * 64u + lane;
         prodv[q] = __dmul_rn(avs[cur.t[u]], cur.bv[u]);
@@ -302,24 +331,28 @@ __global__ void __launch_bounds__(256)
     // the row's values and A entries are used up: the next row is expanded now (its B entries are in
     // flight during the rest of this row, and only half as many registers are live across the loads)
     if (i + 1u < last) {
-      short_expand<true, STEPS>(B, cm, fa, lane, scratch, nxt);
-      if (i + 2u < last) short_fetch<true>(A, B, m, o.c_ptr, rows, i + 2u, lane, fa);
+      short_expand<true, STEPS>(B, cm, fa, lane, scratch, PM, nxt);
+      if (i + 2u < last) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, i + 2u, lane, fa);
     }
-    // 1. sorted insertion; the chains of a lane's products advance together
-    for (;;) {
-      bool open = false;
+    // 1. sorted insertion; the chains of a lane's products advance together: the atomics of a round
+    //    are issued back to back, their results read afterwards, no branch in between (the minimum
+    //    with "empty" changes no slot, so a lane whose chain has ended just keeps going)
+    if (T) // (a lane's slots stay below T, which is at least 64 here)
+      for (;;) {
+        key_t old[STEPS];
 #pragma unroll
-      for (int u = 0; u < STEPS; ++u) {
-        if (x[u] != EMPTY64) {
-          const key_t old = atomicMin(&tab[h[u]], x[u]);
-          if (old > x[u]) x[u] = old; // EMPTY64 ends the chain
-          ++h[u];
-          if (h[u] >= T) x[u] = EMPTY64; // cannot happen: at most `total` entries past the last home slot
+        for (int u = 0; u < STEPS; ++u) old[u] = atomicMin(&tab[h[u]], x[u]);
+        bool open = false;
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+          x[u] = old[u] > x[u] ? old[u] : x[u]; // the larger one is carried on; "empty" ends the chain
+          const bool last_slot = h[u] + 1u >= T; // cannot happen to a chain: at most `total` entries past the last home slot
+          x[u] = last_slot ? EMPTY64 : x[u];
+          h[u] = last_slot ? h[u] : h[u] + 1u;
           open |= x[u] != EMPTY64;
         }
+        if (!__any(open)) break;
       }
-      if (!__any(open)) break;
-    }
     lds_fence();
     // 2. the occupied slots are moved to the front of the table, in slot order (16 bytes of slots per
     //    lane and step; an entry moves to a slot at or before its own, and every lane has read its

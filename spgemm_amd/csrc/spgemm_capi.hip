@@ -62,6 +62,7 @@ struct spgemm_mat {
   size_t bytes_prow = 0;
   uint4 *d_prec = nullptr;    // rows of up to PREC_MAX_LEN entries as padded 16-byte records (short-row numeric kernel)
   size_t bytes_prec = 0;
+  uint64_t prec_slots = 0;    // record slots in d_prec; the padded column array follows them
   uint4 *d_packed = nullptr;  // the entries as 16-byte records {column, 0, value}, read by the big-row numeric kernel
   size_t bytes_packed = 0;
   // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
@@ -106,7 +107,8 @@ struct spgemm_ctx {
   uint32_t short_sym_spread = 1; // short-row symbolic kernel: log2 of (table slots / 2 / products)
   uint32_t analyze_lanes = 0;    // lanes per A row in the analysis (8, 16, 32; 0: chosen by the mean row length)
   uint32_t short_key32 = 1;      // 1: 32-bit table entries in the short-row numeric kernel where B's columns allow
-  uint32_t short_packed = 1;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records
+  uint32_t short_packed = 2;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records; 2: and the
+                                 // count-only symbolic kernel their columns from a padded array of its own
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
   uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
@@ -330,9 +332,13 @@ static int ensure_prec_layout(spgemm_ctx *ctx, const spgemm_mat *B) {
 static int ensure_prec(spgemm_ctx *ctx, const spgemm_mat *B) {
   if (B->d_prec || !B->nnz) return SPGEMM_OK;
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
-  TRY(pool_alloc(ctx, (B->nnz + 7 * std::min<uint64_t>(B->rows, B->nnz)) * sizeof(uint4), (void **)&mb->d_prec, &mb->bytes_prec));
+  // 16 bytes per record slot, then the columns alone at 4 bytes per record slot
+  // (a multiple of 8 slots, so that the column array starts on a 128-byte line as the records do)
+  const uint64_t slots = (B->nnz + 7 * std::min<uint64_t>(B->rows, B->nnz) + 7) & ~(uint64_t)7;
+  TRY(pool_alloc(ctx, slots * (sizeof(uint4) + 4), (void **)&mb->d_prec, &mb->bytes_prec));
+  mb->prec_slots = slots;
   hipLaunchKernelGGL(k_prec_fill, dim3(div_up_u64(B->rows * 8, 256)), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
-                     B->d_val, rowinfo_of(B), mb->d_prec);
+                     B->d_val, rowinfo_of(B), mb->d_prec, reinterpret_cast<uint32_t *>(mb->d_prec + slots));
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -675,7 +681,7 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_key32 must be 0 or 1");
     ctx->short_key32 = (uint32_t)value;
   } else if (n == "short_packed") {
-    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0 or 1");
+    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0, 1 or 2");
     ctx->short_packed = (uint32_t)value;
   } else if (n == "slice_run_min") {
     if (value < 4 || value > 64) return fail(SPGEMM_ERR_INVALID, "slice_run_min must be 4..64");
@@ -1051,7 +1057,8 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   uint64_t *total_nprod = ar.take<uint64_t>(NPROD_SLOTS);
   unsigned long long *zero_count = reinterpret_cast<unsigned long long *>(ar.take<uint64_t>(32 + SLICE_MAX_QUEUES * SLICE_QUEUE_STRIDE));
   uint64_t *r_nprod = ctx->profile >= 2 ? ar.take<uint64_t>(rows) : nullptr;
-  uint64_t *a_p0 = short_aux ? ar.take<uint64_t>(A->nnz) : nullptr;
+  // (with padded records and padded columns both short-row kernels start from a_pk)
+  uint64_t *a_p0 = short_aux && !(short_pk && ctx->short_packed >= 2) ? ar.take<uint64_t>(A->nnz) : nullptr;
   uint32_t *a_len = short_aux ? ar.take<uint32_t>(A->nnz) : nullptr;
   uint64_t *a_pk = short_pk ? ar.take<uint64_t>(A->nnz) : nullptr;
   ctx->r_nprod_prof = r_nprod;
@@ -1144,8 +1151,13 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
         TRY(prof_begin(ctx, 0, 1, 1, cnt, log2s, 0, region * wpb, rows_bin));
         const uint32_t rpw = short_rows_per_wave(ctx, cnt);
         // tier t holds rows of at most 64 << t products: up to 4 steps of 64 products, or 8
+        const uint32_t *pcol = nullptr;
+        if (a_pk && ctx->short_packed >= 2) {
+          TRY(ensure_prec(ctx, B));
+          pcol = reinterpret_cast<const uint32_t *>(B->d_prec + B->prec_slots);
+        }
         hipLaunchKernelGGL(tier <= 2 ? k_sym_count<4> : k_sym_count<SH_STEPS>, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)),
-                           dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s, wpb, rpw);
+                           dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s, wpb, rpw, pcol);
         HIP_TRY(hipGetLastError());
         TRY(prof_end(ctx));
         continue;
@@ -1328,7 +1340,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       const uint32_t wpb = pick_wpb(region);
       TRY(ensure_colcdf(ctx, B));
       if (pl.a_pk) TRY(ensure_prec(ctx, B));
-      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr};
+      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr, nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
       const bool four = num_short_steps(log2pm) == 4;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"window_max_span": 65536, "window_ratio": 128, "hash_max_nprod": 4096, "big_win_words": 32768,
             "slice_blocks": 0, "hash_num_slice": 1024, "row_groups": 1, "flat_walk": 1, "big_rows": 1,
-            "g_thresh2": 24, "lane_order_adds": 1, "slice_queues": 1, "slice_packed": 0, "short_packed": 1, "grp_compact": 2, "short_key32": 1, "analyze_lanes": 0}
+            "g_thresh2": 24, "lane_order_adds": 1, "slice_queues": 1, "slice_packed": 0, "short_packed": 2, "grp_compact": 2, "short_key32": 1, "analyze_lanes": 0}
 
 
 def to_o(h):
@@ -73,7 +73,7 @@ def test_random_structure_and_options(seed):
     opts["lane_order_adds"] = int(rng.integers(0, 3) != 0)  # 0: claim rounds instead of one ordered LDS add
     opts["slice_queues"] = int(rng.choice([1, 3, 8]))
     opts["slice_packed"] = int(rng.integers(0, 2))
-    opts["short_packed"] = int(rng.integers(0, 3) != 0)
+    opts["short_packed"] = int(rng.integers(0, 3))
     opts["grp_compact"] = int(rng.integers(0, 3))
     opts["short_key32"] = int(rng.integers(0, 2))
     opts["analyze_lanes"] = int(rng.choice([0, 8, 16, 32]))
