@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256)
       for (int u = 0; u < STEPS; ++u) {
         mine += (old[u] == EMPTY_KEY && c[u] != EMPTY_KEY) ? 1u : 0u;
         c[u] = (old[u] == EMPTY_KEY || old[u] == c[u]) ? EMPTY_KEY : c[u];
-        h[u] = (h[u] + 1u) & mask; // the table is at most half full: an empty slot comes
+        h[u] = c[u] != EMPTY_KEY ? (h[u] + 1u) & mask : lane; // the table is at most half full: an empty slot comes
         open |= c[u] != EMPTY_KEY;
       }
       if (!__any(open)) break;
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256)
           x[u] = old[u] > x[u] ? old[u] : x[u]; // the larger one is carried on; "empty" ends the chain
           const bool last_slot = h[u] + 1u >= T; // cannot happen to a chain: at most `total` entries past the last home slot
           x[u] = last_slot ? EMPTY64 : x[u];
-          h[u] = last_slot ? h[u] : h[u] + 1u;
+          h[u] = x[u] != EMPTY64 ? h[u] + 1u : lane;
           open |= x[u] != EMPTY64;
         }
         if (!__any(open)) break;
