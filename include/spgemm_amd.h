@@ -121,7 +121,7 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   run_min (4..64), one more per run_div A entries
  *   slice_sorted                                    1: its work items are taken in the order of their
  *                                                   first output column instead of row by row
- *   slice_packed                                    1: it reads B as 16-byte {column, value} records
+ *   slice_packed                                    1: it reads B as 12-byte {column, value} records
  *                                                   (built once per B handle)
  *   lane_order_adds                                 1 (default): where the device passed the probe run
  *                                                   by spgemm_create (one LDS fp64 add applies lanes

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256)
 }
 
 // first position in [lo, hi) of B.col whose column is >= key (per lane)
-// STRIDE: distance of consecutive columns in `col`, in uint32 (4 for the packed {column, value} records)
+// STRIDE: distance of consecutive columns in `col`, in uint32 (3 for the packed {column, value} records)
 template <int STRIDE = 1>
 __device__ __forceinline__ uint64_t lower_bound_col(const uint32_t *__restrict__ col, uint64_t lo, uint64_t hi,
                                                     uint64_t key) {
@@ -393,17 +393,17 @@ constexpr uint32_t SLICE_QUEUE_STRIDE = 16; // counters, in uint64: one 128-byte
 __global__ void __launch_bounds__(64)
     k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
                 NumOut o, unsigned long long *__restrict__ work, unsigned char *__restrict__ list_scratch,
-                uint64_t list_cap, uint64_t nnz_b, const uint4 *__restrict__ packed, uint32_t queues, uint32_t hw_order) {
-  // the entries of B as 16-byte records {column, -, value}: a short piece of a row of B (a few entries,
-  // the common case inside a chunk) then lies in ONE 128-byte line instead of one line of columns and
-  // one of values, and this kernel is bound by the lines it pulls in
+                uint64_t list_cap, uint64_t nnz_b, const Rec12 *__restrict__ packed, uint32_t queues, uint32_t hw_order) {
+  // the entries of B as 12-byte records {column, value} (optional): a short piece of a row of B (a few
+  // entries, the common case inside a chunk) then lies in one 128-byte line, or two, instead of one
+  // line of columns and one of values, and this kernel is bound by the lines it pulls in
   const uint32_t *__restrict__ pcol = reinterpret_cast<const uint32_t *>(packed);
-  auto bcol = [&](uint64_t i) -> uint32_t { return packed ? pcol[i * 4u] : B.col[i]; };
+  auto bcol = [&](uint64_t i) -> uint32_t { return packed ? pcol[i * 3u] : B.col[i]; };
   auto bpair = [&](uint64_t i, uint32_t &c, double &v) {
     if (packed) {
-      const uint4 t = packed[i];
-      c = t.x;
-      v = __longlong_as_double((long long)(((unsigned long long)t.w << 32) | t.z));
+      const Rec12 t = packed[i];
+      c = t.col;
+      v = __longlong_as_double((long long)(((unsigned long long)t.val_hi << 32) | t.val_lo));
     } else {
 #if defined(SG_ABL_COL)  // diagnostic builds: the loads of one kind go to a cache-resident kilobyte (wrong results)
       c = B.col[i & 1023u];
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64)
     }
   };
   auto lbound = [&](uint64_t lo, uint64_t hi, uint64_t key) {
-    return packed ? lower_bound_col<4>(pcol, lo, hi, key) : lower_bound_col<1>(B.col, lo, hi, key);
+    return packed ? lower_bound_col<3>(pcol, lo, hi, key) : lower_bound_col<1>(B.col, lo, hi, key);
   };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *scol = reinterpret_cast<uint32_t *>(smem);
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(64)
             hi[u] = item_first ? lo[u] : b1[u]; // empty range: nothing to search
           }
         }
-        if (packed) lower_bound_col_n<U, 4>(pcol, lo, hi, clo_item);
+        if (packed) lower_bound_col_n<U, 3>(pcol, lo, hi, clo_item);
         else lower_bound_col_n<U, 1>(B.col, lo, hi, clo_item);
 #pragma unroll
         for (int u = 0; u < U; ++u) {

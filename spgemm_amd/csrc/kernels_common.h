@@ -41,6 +41,12 @@ struct ClassParams {
   uint32_t g_thresh0, g_thresh1, g_thresh2; // mean B-row length thresholds for 8/16/32 lanes
   uint32_t short_max_nprod; // rows of the hash path with at most this many products take the short-row kernels (0: none)
 };
+// an entry of B as a 12-byte record {column, value}: as many bytes as the two arrays hold, and a short
+// piece of a row lies in one 128-byte line (or two) instead of one of columns and one of values
+struct __attribute__((packed, aligned(4))) Rec12 {
+  uint32_t col, val_lo, val_hi;
+};
+
 // Short rows (kernels_short.h): at most SH_MAX_NPROD products and SH_MAX_ALEN entries in the A row.
 // In the hash bins sub-bin 0 (key & 3 == 0) is theirs alone; the other rows use sub-bins 1..3.
 constexpr uint32_t SH_MAX_NPROD = 512, SH_MAX_ALEN = 64;

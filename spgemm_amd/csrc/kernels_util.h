@@ -198,10 +198,10 @@ __global__ void __launch_bounds__(256) k_probe_lane_order(uint32_t trials, unsig
 
 // ---- B as 16-byte records {column, 0, value} (read by the big-row numeric kernel) ---------------------
 __global__ void __launch_bounds__(256)
-    k_pack_records(uint64_t nnz, const uint32_t *__restrict__ col, const double *__restrict__ val, uint4 *__restrict__ out) {
+    k_pack_records(uint64_t nnz, const uint32_t *__restrict__ col, const double *__restrict__ val, Rec12 *__restrict__ out) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long v = (unsigned long long)__double_as_longlong(val[i]);
-    out[i] = make_uint4(col[i], 0u, (uint32_t)v, (uint32_t)(v >> 32));
+    out[i] = Rec12{col[i], (uint32_t)v, (uint32_t)(v >> 32)};
   }
 }
 

@@ -63,7 +63,7 @@ struct spgemm_mat {
   uint4 *d_prec = nullptr;    // rows of up to PREC_MAX_LEN entries as padded 16-byte records (short-row numeric kernel)
   size_t bytes_prec = 0;
   uint64_t prec_slots = 0;    // record slots in d_prec; the padded column array follows them
-  uint4 *d_packed = nullptr;  // the entries as 16-byte records {column, 0, value}, read by the big-row numeric kernel
+  Rec12 *d_packed = nullptr;  // the entries as 12-byte records {column, value}, read by the big-row numeric kernel (option)
   size_t bytes_packed = 0;
   // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
   std::vector<uint64_t> h_ptr;  // host copy of the row pointer
@@ -112,7 +112,7 @@ struct spgemm_ctx {
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
   uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
-  uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 16-byte {column, value} records
+  uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 12-byte {column, value} records
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
@@ -348,7 +348,7 @@ static int ensure_prec(spgemm_ctx *ctx, const spgemm_mat *B) {
 static int ensure_packed(spgemm_ctx *ctx, const spgemm_mat *B) {
   if (B->d_packed || !B->nnz) return SPGEMM_OK;
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
-  TRY(pool_alloc(ctx, B->nnz * sizeof(uint4), (void **)&mb->d_packed, &mb->bytes_packed));
+  TRY(pool_alloc(ctx, B->nnz * sizeof(Rec12) + 16, (void **)&mb->d_packed, &mb->bytes_packed));
   const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(B->nnz, 256), (uint64_t)ctx->cu_count * 16);
   hipLaunchKernelGGL(k_pack_records, dim3(blocks), dim3(256), 0, ctx->stream, B->nnz, B->d_col, B->d_val, mb->d_packed);
   HIP_TRY(hipGetLastError());
