@@ -78,6 +78,40 @@ def test_erdos_renyi(ctx, n):
         assert st["rows_hash"] > 0
 
 
+@pytest.mark.parametrize("len_b", [1, 4, 5, 8, 9, 16, 17])
+def test_short_rows_slot_layout_boundaries(len_b):
+    """Short rows at the edges of the layout that gives every A entry a fixed slot of 4, 8 or 16
+    lanes (B rows of exactly 4 / 5 / 8 / 9 / 16 / 17 entries, A rows of 1 to 64 entries, so that
+    entries * slot falls on either side of the 256- and 512-product limits), with duplicates and
+    cancellations among the products, under both table widths and with and without the padded layouts."""
+    rng = np.random.default_rng(77 + len_b)
+    k, n = 3000, 200_000
+    # B: every row exactly len_b entries, columns from a pool of 600 so that products collide
+    pool = np.sort(rng.choice(n, 600, replace=False))
+    bc = np.concatenate([np.sort(rng.choice(pool, len_b, replace=False)) for _ in range(k)])
+    br = np.repeat(np.arange(k), len_b)
+    bv = rng.integers(-2, 3, len(br)).astype(np.float64)
+    bv[bv == 0] = 1.0
+    B = hostcsr.HostCsr.from_coo(k, n, br, bc, bv).sorted_rows()
+    lens = [1, 2, 4, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64] * 8
+    ar = np.repeat(np.arange(len(lens)), lens)
+    ac = np.concatenate([np.sort(rng.choice(k, l, replace=False)) for l in lens])
+    av = rng.integers(-2, 3, len(ar)).astype(np.float64)
+    av[av == 0] = 1.0
+    A = hostcsr.HostCsr.from_coo(len(lens), k, ar, ac, av).sorted_rows()
+    for key32 in (1, 0):
+        for packed in (2, 0):
+            c = capi.Context(0)
+            try:
+                c.set_option("window_max_span", 0)  # nothing takes the window path
+                c.set_option("short_key32", key32)
+                c.set_option("short_packed", packed)
+                _, st = check(c, A, B)
+                assert st["rows_hash"] > 0
+            finally:
+                c.close()
+
+
 def test_rmat_default_paths(ctx):
     A = hostcsr.rmat(13, 8, seed=1)
     check(ctx, A, A)
