@@ -102,6 +102,9 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   grp_compact                                     row-group numeric kernel: 1 two-level bitmap over
  *                                                   the column hull (less LDS), 0 flat bitmap (fewer
  *                                                   instructions), 2 (default) chosen per launch
+ *   walk_tail                                       window kernels fetch entries 64..127 of a row of B
+ *                                                   ahead with its first 64: 0 no, 1 yes, 2 (default)
+ *                                                   where B's rows hold 48 entries and more on average
  *   short_packed                                    1: the numeric one reads the rows of B as 16-byte
  *                                                   {column, value} records padded to 128-byte lines
  *                                                   (built once per B handle, at most 7 records of

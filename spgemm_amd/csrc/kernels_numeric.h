@@ -126,7 +126,7 @@ __host__ __device__ inline size_t grp_region(bool compact, uint32_t words, uint3
 __host__ __device__ inline bool grp_use_compact(uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
   return (size_t)words * 8u * 3u > grp_region(false, words, cap, gmax, alen);
 }
-template <int TIER, bool COMPACT>
+template <int TIER, bool COMPACT, bool TAIL = false> // TAIL: see RowWalk
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
                      uint32_t words, uint32_t cap, uint32_t wpb, uint32_t gmax) {
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t n = scalar_view((const uint32_t *)m.nnz)[row];
   const uint32_t *tin = m.temp_cols + scalar_view(m.t_off)[row];
   // first loads of the B walk, overlapped with the LDS set-up below
-  RowWalk<true, false> walk;
+  RowWalk<true, false, TAIL> walk;
   walk.begin(A, B, row, lane);
   const uint32_t len_a = (uint32_t)(walk.a1 - walk.a0);
   // lane j holds the output offset and the A offset of the group's j-th row

@@ -19,7 +19,7 @@ namespace sg {
 __host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
   return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
 }
-template <bool FLAT>
+template <bool FLAT, bool TAIL = false> // TAIL: see RowWalk (scalar walk only)
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
                  uint32_t words) {
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256)
     atomicOr(&bm[c >> 5], 1u << (c & 31u));
   };
   if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + sym_window_region(words, false), mark);
-  else wave_row_walk<false>(A, B, row, lane, mark);
+  else wave_row_walk<false, false, TAIL>(A, B, row, lane, mark);
   lds_fence();
   // per-word prefix of the set-bit counts (16 bits: the hull of the window path is at most 65,536
   // columns wide, so fewer than 65,536 bits lie before any word)

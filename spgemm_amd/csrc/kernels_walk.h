@@ -105,40 +105,49 @@ __device__ __forceinline__ void walk_scalar_stage(const Csr &A, const Csr &B, ui
   for (int u = 0; u < PF; ++u) s.len[u] = (ka + u < a1) ? (uint32_t)(p1[u] - s.p0[u]) : 0u;
 }
 
-template <bool WITH_VAL, bool WITH_AVAL>
+// TAIL: entries 64..127 of every B row are fetched here as well (c2, v2) instead of by the consumer.
+template <bool WITH_VAL, bool WITH_AVAL, bool TAIL>
 __device__ __forceinline__ void walk_vector_stage(const Csr &B, const WalkInfo<WITH_AVAL> &s, uint32_t lane,
-                                                  uint32_t (&c)[PF], double (&v)[PF]) {
+                                                  uint32_t (&c)[PF], double (&v)[PF], uint32_t (&c2)[PF], double (&v2)[PF]) {
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const bool ok = lane < s.len[u];
     c[u] = ok ? (B.col + s.p0[u])[lane] : EMPTY_KEY;
     if constexpr (WITH_VAL) v[u] = ok ? (B.val + s.p0[u])[lane] : 0.0;
+    if constexpr (TAIL) {
+      const bool ok2 = lane + 64u < s.len[u];
+      c2[u] = ok2 ? (B.col + s.p0[u])[lane + 64u] : EMPTY_KEY;
+      if constexpr (WITH_VAL) v2[u] = ok2 ? (B.val + s.p0[u])[lane + 64u] : 0.0;
+    }
   }
 }
 
 // begin() issues the first loads of the walk (two scalar stages and one vector stage) so that a
 // kernel can overlap them with its LDS set-up; run() consumes the row.
-template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL> struct RowWalk {
+// TAIL: entries 64..127 of a B row are fetched ahead with the first 64 (8 or 24 more registers); without
+// it the consumer loads everything past the first 64 itself, with the latency exposed.  Pays where B's
+// rows are mostly longer than a wavefront.
+template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false> struct RowWalk {
   uint64_t a0, a1;
   WalkInfo<WITH_AVAL> s_cur, s_next;
-  uint32_t c_cur[PF];
-  double v_cur[PF];
+  uint32_t c_cur[PF], c2_cur[PF];
+  double v_cur[PF], v2_cur[PF];
 
   __device__ __forceinline__ void begin(const Csr &A, const Csr &B, uint32_t row, uint32_t lane) {
     const auto a_ptr = scalar_view(A.ptr);
     a0 = a_ptr[row];
     a1 = a_ptr[row + 1];
     walk_scalar_stage<WITH_AVAL>(A, B, a0, a1, s_cur);
-    walk_vector_stage<WITH_VAL, WITH_AVAL>(B, s_cur, lane, c_cur, v_cur);
+    walk_vector_stage<WITH_VAL, WITH_AVAL, TAIL>(B, s_cur, lane, c_cur, v_cur, c2_cur, v2_cur);
     walk_scalar_stage<WITH_AVAL>(A, B, a0 + PF, a1, s_next);
   }
 
   template <class F> __device__ __forceinline__ void run(const Csr &A, const Csr &B, uint32_t lane, F f) {
     WalkInfo<WITH_AVAL> s_after;
-    uint32_t c_next[PF];
-    double v_next[PF];
+    uint32_t c_next[PF], c2_next[PF];
+    double v_next[PF], v2_next[PF];
     for (uint64_t ka = a0; ka < a1; ka += PF) {
-      walk_vector_stage<WITH_VAL, WITH_AVAL>(B, s_next, lane, c_next, v_next);
+      walk_vector_stage<WITH_VAL, WITH_AVAL, TAIL>(B, s_next, lane, c_next, v_next, c2_next, v2_next);
       walk_scalar_stage<WITH_AVAL>(A, B, ka + 2 * PF, a1, s_after);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -147,7 +156,12 @@ template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL> struct RowWalk {
         if (s_cur.len[u] > 64) { // wave-uniform: the rest of a long B row, before the next A entry
           const uint32_t *pc = B.col + s_cur.p0[u];
           const double *pv = B.val + s_cur.p0[u];
-          for (uint32_t j = 64 + lane; j < s_cur.len[u]; j += 64)
+          uint32_t j0 = 64;
+          if constexpr (TAIL) {
+            if (c2_cur[u] != EMPTY_KEY) f(c2_cur[u], WITH_VAL ? v2_cur[u] : 0.0, WITH_AVAL ? s_cur.av[u] : 0.0, apos);
+            j0 = 128;
+          }
+          for (uint32_t j = j0 + lane; j < s_cur.len[u]; j += 64)
             f(pc[j], WITH_VAL ? pv[j] : 0.0, WITH_AVAL ? s_cur.av[u] : 0.0, apos);
         }
       }
@@ -157,14 +171,18 @@ template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL> struct RowWalk {
       for (int u = 0; u < PF; ++u) {
         c_cur[u] = c_next[u];
         v_cur[u] = v_next[u];
+        if constexpr (TAIL) {
+          c2_cur[u] = c2_next[u];
+          v2_cur[u] = v2_next[u];
+        }
       }
     }
   }
 };
 
-template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, class F>
+template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false, class F>
 __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
-  RowWalk<WITH_VAL, WITH_AVAL> w;
+  RowWalk<WITH_VAL, WITH_AVAL, TAIL> w;
   w.begin(A, B, row, lane);
   w.run(A, B, lane, f);
 }

@@ -107,6 +107,8 @@ struct spgemm_ctx {
   uint32_t short_sym_spread = 1; // short-row symbolic kernel: log2 of (table slots / 2 / products)
   uint32_t analyze_lanes = 0;    // lanes per A row in the analysis (8, 16, 32; 0: chosen by the mean row length)
   uint32_t short_key32 = 1;      // 1: 32-bit table entries in the short-row numeric kernel where B's columns allow
+  uint32_t walk_tail = 2;        // scalar walk of the window kernels fetches entries 64..127 of a B row ahead: 0 no, 1 yes,
+                                 // 2 where B's rows hold 48 entries and more on average
   uint32_t short_packed = 2;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records; 2: and the
                                  // count-only symbolic kernel their columns from a padded array of its own
   uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
@@ -178,6 +180,10 @@ static constexpr size_t NOALLOC_PARTIAL_BYTES =
 static __device__ __align__(256) unsigned char scratch[NOALLOC_LEN_BYTES + NOALLOC_PARTIAL_BYTES];
 
 // ---- helpers ------------------------------------------------------------------------------------
+static bool walk_tail(const spgemm_ctx *ctx, const spgemm_mat *B) {
+  return ctx->walk_tail == 2 ? B->nnz >= 48 * B->rows : ctx->walk_tail != 0;
+}
+
 static int set_device(const spgemm_ctx *ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
   return SPGEMM_OK;
@@ -405,9 +411,11 @@ template <class K> static void raise_lds_limit(K kernel) {
   (void)hipGetLastError(); // a refusal shows again, with the kernel's name, at the launch that needs the room
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
-  raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>);
+  raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>); raise_lds_limit(k_sym_window<false, true>);
   raise_lds_limit(k_num_window_grp<0, false>); raise_lds_limit(k_num_window_grp<1, false>); raise_lds_limit(k_num_window_grp<2, false>);
   raise_lds_limit(k_num_window_grp<0, true>); raise_lds_limit(k_num_window_grp<1, true>); raise_lds_limit(k_num_window_grp<2, true>);
+  raise_lds_limit(k_num_window_grp<0, false, true>); raise_lds_limit(k_num_window_grp<1, false, true>); raise_lds_limit(k_num_window_grp<2, false, true>);
+  raise_lds_limit(k_num_window_grp<0, true, true>); raise_lds_limit(k_num_window_grp<1, true, true>); raise_lds_limit(k_num_window_grp<2, true, true>);
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
@@ -680,6 +688,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "short_key32") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "short_key32 must be 0 or 1");
     ctx->short_key32 = (uint32_t)value;
+  } else if (n == "walk_tail") {
+    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "walk_tail must be 0, 1 or 2");
+    ctx->walk_tail = (uint32_t)value;
   } else if (n == "short_packed") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0, 1 or 2");
     ctx->short_packed = (uint32_t)value;
@@ -1138,7 +1149,10 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       uint32_t wpb = pick_wpb(region);
       st.rows_window += cnt;
       TRY(prof_begin(ctx, 0, 0, flat ? 0 : 64, cnt, words, 0, region * wpb, rows_bin));
-      hipLaunchKernelGGL(flat ? k_sym_window<true> : k_sym_window<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
+      auto sym_kern = k_sym_window<false, false>;
+      if (flat) sym_kern = k_sym_window<true, false>;
+      else if (walk_tail(ctx, B)) sym_kern = k_sym_window<false, true>;
+      hipLaunchKernelGGL(sym_kern, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
@@ -1328,6 +1342,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
       auto kern = compact ? (tier == 0 ? k_num_window_grp<0, true> : tier == 1 ? k_num_window_grp<1, true> : k_num_window_grp<2, true>)
                           : (tier == 0 ? k_num_window_grp<0, false> : tier == 1 ? k_num_window_grp<1, false> : k_num_window_grp<2, false>);
+      if (walk_tail(ctx, B))
+        kern = compact ? (tier == 0 ? k_num_window_grp<0, true, true> : tier == 1 ? k_num_window_grp<1, true, true> : k_num_window_grp<2, true, true>)
+                       : (tier == 0 ? k_num_window_grp<0, false, true> : tier == 1 ? k_num_window_grp<1, false, true> : k_num_window_grp<2, false, true>);
       hipLaunchKernelGGL(kern,
                          dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb, gmax);
