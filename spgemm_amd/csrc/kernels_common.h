@@ -32,6 +32,7 @@ constexpr uint32_t GRP_MAX_WIDE = 4, GRP_ALEN_WIDE = 128;
 // the smaller of the two wide tiers: A rows of up to GRP_ALEN_MID entries and up to GRP_CAP_MID outputs
 // (3 x 27 = 81 entries and 3 x 125 = 375 outputs: three unknowns per node of a 3-D grid)
 constexpr uint32_t GRP_ALEN_MID = 96, GRP_CAP_MID = 384;
+constexpr uint32_t GRP_CAP_TOP = 512; // most outputs a grouped row can have (the largest `cap` of the group kernel)
 __host__ __device__ inline uint32_t group_max_rows(uint64_t len_a) { return len_a > GRP_ALEN ? GRP_MAX_WIDE : GRP_MAX; }
 
 struct ClassParams {

@@ -181,15 +181,25 @@ __global__ void __launch_bounds__(256)
         if (64u + lane < len_a) av_hi[j] = av[64u + lane];
     }
   }
-  lds_fence();
-  for (uint32_t p = lane; p < n; p += 64) {
-    uint32_t c = tin[p];
+  // the group's column list (at most GRP_CAP_TOP entries), loaded in one go: it is used twice below, and
+  // a loop with a load per round pays the round trip every time
+  constexpr uint32_t TCN = GRP_CAP_TOP / 64;
+  uint32_t tc[TCN];
 #pragma unroll
-    for (uint32_t j = 0; j < GRP_MAX; ++j)
-      if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
-    const uint32_t cc = c - base, wi = cc >> 5;
-    if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
-    else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
+  for (uint32_t u = 0; u < TCN; ++u) tc[u] = 64u * u + lane < n ? tin[64u * u + lane] : 0u;
+  lds_fence();
+#pragma unroll
+  for (uint32_t u = 0; u < TCN; ++u) {
+    const uint32_t p = 64u * u + lane;
+    if (64u * u < n && p < n) { // (the first test is wave-uniform)
+      const uint32_t c = tc[u];
+#pragma unroll
+      for (uint32_t j = 0; j < GRP_MAX; ++j)
+        if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
+      const uint32_t cc = c - base, wi = cc >> 5;
+      if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
+      else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
+    }
   }
   lds_fence();
   uint32_t ncw = nw;
@@ -209,10 +219,12 @@ __global__ void __launch_bounds__(256)
       ncw += group_last<64>(incl);
     }
     lds_fence();
-    for (uint32_t p = lane; p < n; p += 64) {
-      const uint32_t cc = tin[p] - base;
-      atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
-    }
+#pragma unroll
+    for (uint32_t u = 0; u < TCN; ++u)
+      if (64u * u < n && 64u * u + lane < n) {
+        const uint32_t cc = tc[u] - base;
+        atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
+      }
     lds_fence();
   }
   uint32_t carry = 0;

@@ -1332,7 +1332,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
     if (key >= NUM_GRP0) {
       uint32_t st_ = (uint32_t)(key - NUM_GRP0) >> 2, q = (uint32_t)(key - NUM_GRP0) & 3;
       const int tier = q < 2 ? 0 : q == 2 ? 1 : 2; // 0: up to 8 rows; 1, 2: wide groups (see num_key_of)
-      uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : 512u;
+      uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : GRP_CAP_TOP;
       const uint32_t gmax = tier ? pl.gmax_wide : pl.gmax_narrow;
       const uint32_t alen = tier == 0 ? GRP_ALEN : tier == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
       const bool compact = ctx->grp_compact == 2 ? grp_use_compact(words, cap, gmax, alen) : ctx->grp_compact != 0;
