@@ -310,12 +310,34 @@ __global__ void __launch_bounds__(256)
   }
   // largest group of the multiply, narrow ([0]) and wide ([1]) rows apart: the group kernel sizes its
   // LDS by it (five unknowns per mesh node make groups of five, not of GRP_MAX)
-  const uint32_t mn = group_max<64>(wide ? 0u : c), mw = group_max<64>(wide ? c : 0u);
-  if ((threadIdx.x & 63u) == 0) {
+  // A row by itself counts as no group (the host takes the maximum to be at least 1), so a matrix
+  // without groups issues no atomic at all; the others one per workgroup: thousands of wavefronts
+  // on one address took longer than the rest of this kernel.
+  __shared__ uint32_t s_mn[4], s_mw[4];
+  const uint32_t mn = group_max<64>(wide || c < 2u ? 0u : c), mw = group_max<64>(wide && c >= 2u ? c : 0u);
+  if ((threadIdx.x & 63u) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mw[threadIdx.x >> 6] = mw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t bn = max(max(s_mn[0], s_mn[1]), max(s_mn[2], s_mn[3]));
+    const uint32_t bw = max(max(s_mw[0], s_mw[1]), max(s_mw[2], s_mw[3]));
     // the reads only save atomics; they bypass the CU's cache, which would keep showing zero
-    if (mn > __hip_atomic_load(&gmax_seen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[0], mn);
-    if (mw > __hip_atomic_load(&gmax_seen[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[1], mw);
+    if (bn && bn > __hip_atomic_load(&gmax_seen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[0], bn);
+    if (bw && bw > __hip_atomic_load(&gmax_seen[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&gmax_seen[1], bw);
   }
+}
+
+// ---- start of a multiply: the counters and the per-row arrays that must start from a known value ---
+// One launch instead of four fills (each of which is a launch or two of its own): zero[0..n_zero)
+// = 0, nnz[0..rows) = 0, numkey[0..rows) = 0xFF.  nnz and numkey start on 256-byte boundaries and
+// own the bytes up to the next one, so they are written 16 bytes at a time.
+__global__ void __launch_bounds__(256)
+    k_sym_clear(uint32_t *__restrict__ zero_a, uint32_t n_zero_a, uint32_t *__restrict__ zero_b, uint32_t n_zero_b,
+                uint4 *__restrict__ nnz16, uint32_t n_nnz16, uint4 *__restrict__ numkey16, uint32_t n_numkey16) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  for (uint32_t j = i; j < n_zero_a; j += stride) zero_a[j] = 0u;
+  for (uint32_t j = i; j < n_zero_b; j += stride) zero_b[j] = 0u;
+  for (uint32_t j = i; j < n_nnz16; j += stride) nnz16[j] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t j = i; j < n_numkey16; j += stride) numkey16[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
 }
 
 // ---- exclusive scan (uint32 in, uint64 out), three launches ----------------------------------
@@ -454,9 +476,13 @@ __global__ void __launch_bounds__(PART_BLOCK)
 // blk_off = exclusive scan of blk_hist (bin-major), so bin b starts at blk_off[b*nblocks].
 __global__ void __launch_bounds__(PART_BLOCK)
     k_part_scatter(const uint8_t *__restrict__ key, uint32_t n, uint32_t nbins, uint32_t nblocks,
-                   const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ rows_out) {
+                   const uint64_t *__restrict__ blk_off, uint32_t *__restrict__ rows_out,
+                   uint64_t *__restrict__ bin_off) {
   __shared__ uint32_t s_base[MAX_BINS];
   __shared__ uint32_t s_wcnt[4][MAX_BINS];
+  // bin_off[b] = start of bin b in rows_out (b = 0..nbins), read from the scanned histogram
+  if (blockIdx.x == 0)
+    for (uint32_t b = threadIdx.x; b <= nbins; b += PART_BLOCK) bin_off[b] = blk_off[(size_t)b * nblocks];
   for (uint32_t b = threadIdx.x; b < nbins; b += PART_BLOCK)
     s_base[b] = (uint32_t)blk_off[(size_t)b * nblocks + blockIdx.x];
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -490,13 +516,6 @@ __global__ void __launch_bounds__(PART_BLOCK)
       s_base[b] += s_wcnt[0][b] + s_wcnt[1][b] + s_wcnt[2][b] + s_wcnt[3][b];
     __syncthreads();
   }
-}
-
-// bin_off[b] = start of bin b in rows_out (b = 0..nbins), read from the scanned histogram.
-__global__ void k_part_binoff(const uint64_t *__restrict__ blk_off, uint32_t nbins, uint32_t nblocks,
-                              uint64_t *__restrict__ bin_off) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b <= nbins) bin_off[b] = blk_off[(size_t)b * nblocks];
 }
 
 } // namespace sg

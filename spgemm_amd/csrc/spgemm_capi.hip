@@ -287,9 +287,7 @@ static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uin
   hipLaunchKernelGGL(k_part_hist, dim3(nb), dim3(PART_BLOCK), 0, ctx->stream, key, n, nbins, nb, ps.blk_hist);
   TRY(launch_scan(ctx, ps.blk_hist, (uint64_t)nbins * nb, ps.blk_off, ps.partial));
   hipLaunchKernelGGL(k_part_scatter, dim3(nb), dim3(PART_BLOCK), 0, ctx->stream, key, n, nbins, nb, ps.blk_off,
-                     rows_out);
-  hipLaunchKernelGGL(k_part_binoff, dim3(1), dim3(MAX_BINS + 1 <= 256 ? 256 : 512), 0, ctx->stream, ps.blk_off, nbins,
-                     nb, bin_off);
+                     rows_out, bin_off);
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -1078,10 +1076,13 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   ctx->arena_used = ar.used;
   if (ar.used > ar.cap) return fail(SPGEMM_ERR_STATE, "internal: arena layout exceeds its size");
 
-  HIP_TRY(hipMemsetAsync(long_count, 0, 256, ctx->stream));
-  HIP_TRY(hipMemsetAsync(total_nprod, 0, NPROD_SLOTS * 8, ctx->stream));
-  HIP_TRY(hipMemsetAsync(r_nnz, 0, (size_t)rows * 4, ctx->stream));
-  HIP_TRY(hipMemsetAsync(r_numkey, 0xFF, (size_t)rows, ctx->stream));
+  {
+    const uint32_t n_nnz16 = div_up_u64((uint64_t)rows * 4, 16), n_key16 = div_up_u64(rows, 16);
+    hipLaunchKernelGGL(k_sym_clear, dim3(std::min<uint32_t>(div_up_u64(std::max<uint32_t>(n_nnz16, 64), 256), 2048)),
+                       dim3(256), 0, ctx->stream, long_count, 64u, reinterpret_cast<uint32_t *>(total_nprod),
+                       (uint32_t)(NPROD_SLOTS * 2), reinterpret_cast<uint4 *>(r_nnz), n_nnz16,
+                       reinterpret_cast<uint4 *>(r_numkey), n_key16);
+  }
 
   AnalyzeOut ao{r_cmin, r_cmax, r_ub, r_key, r_nprod, total_nprod, long_rows, long_count, r_same, a_p0, a_len, a_pk};
   // lanes per A row: measured, not derived - rows of a few dozen entries and more whose B rows
