@@ -401,6 +401,25 @@ __global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *partial, uint32_t
   if (threadIdx.x == 0) partial[nparts] = s_carry;
 }
 
+// The whole scan in one workgroup, for inputs of up to SCAN_SMALL_MAX items (the block histograms of
+// a partition, the rows of a small matrix): one launch instead of two.  Every thread owns a
+// contiguous span.
+constexpr uint32_t SCAN_SMALL_MAX = 16384;
+__global__ void __launch_bounds__(1024)
+    k_scan_small(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
+  __shared__ uint64_t s_wave[16];
+  const uint32_t per = (n + 1023u) >> 10, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+  uint64_t s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += in[i];
+  uint64_t tot;
+  uint64_t ex = block_excl_scan64(s, s_wave, &tot);
+  for (uint32_t i = lo; i < hi; ++i) {
+    out[i] = ex;
+    ex += in[i];
+  }
+  if (threadIdx.x == 0) out[n] = tot;
+}
+
 // out[i] = exclusive prefix; out[n] = total.  Items are laid out thread-contiguous here so the
 // per-thread prefix is a running sum.
 // own_spine: `partial` holds the workgroups' raw totals (k_scan_spine has not run) and every

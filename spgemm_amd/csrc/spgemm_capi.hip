@@ -262,6 +262,11 @@ static uint32_t div_up_u64(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 
 static uint32_t scan_parts(uint64_t n) { return div_up_u64(n ? n : 1, (uint64_t)SCAN_BLOCK * SCAN_ITEMS); }
 
 static int launch_scan(spgemm_ctx *ctx, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *partial) {
+  if (n <= SCAN_SMALL_MAX && reinterpret_cast<const void *>(in) != reinterpret_cast<const void *>(out)) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in, (uint32_t)n, out);
+    HIP_TRY(hipGetLastError());
+    return SPGEMM_OK;
+  }
   uint32_t nparts = scan_parts(n);
   hipLaunchKernelGGL(k_scan_partials, dim3(nparts), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, partial);
   const uint32_t own_spine = nparts <= SCAN_OWN_SPINE_MAX ? 1u : 0u;

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# glibc writes the reason of an abort of its own (a failed heap check) to the terminal, which a test
+# run on a GPU box does not have: send it to standard error, where the log keeps it.
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 # PyTorch ships its own copy of the HIP runtime.  A process that uses both torch and
 # libspgemm_amd.so must load torch first: the library then binds to the runtime torch brought; the
 # other way round two runtimes end up in the process and torch finds no GPU.
