@@ -11,14 +11,17 @@ constexpr uint32_t KEY_NONE = 255u; // row needs no kernel (no products)
 
 // ---- bin keys ------------------------------------------------------------------------------
 // symbolic:  [0,24)  window, key = span_tier*4 + gsel, span <= 2048 << span_tier
-//            [24,52) hash,   key = 24 + tier*4 + gsel, nprod <= 64 << tier (table of 128 << tier slots)
-//            [52,56) global, key = 52 + gsel
+//            [24,56) hash,   key = 24 + tier*4 + gsel, nprod <= 64 << tier (table of 128 << tier slots);
+//                    the last tier (up to 8192 products, a table of 128 KiB) only for rows whose B rows
+//                    are long (gsel 3): a whole workgroup shares the table and walks them
+//            [56,60) global, key = 56 + gsel
 // numeric:   [0,96)   window, key = (span_tier*4 + cap_tier)*4 + gsel, nnz <= 128 << (2*cap_tier)
-//            [96,124) hash,   key = 96 + tier*4 + gsel,                 nnz <= 64 << tier
-//            124      global
-//            [125,149) window, row groups: key = 125 + span_tier*4 + cap_tier (one wavefront per group
+//            [96,128) hash,   key = 96 + tier*4 + gsel,                 nnz <= 64 << tier (<= 4096)
+//            128      global
+//            [129,153) window, row groups: key = 129 + span_tier*4 + cap_tier (one wavefront per group
 //                      of up to GRP_MAX consecutive rows of A with identical column lists)
-constexpr int HASH_TIERS = 7; // table sizes 128 << tier
+constexpr int HASH_TIERS = 8; // table sizes 128 << tier
+constexpr uint32_t HASH_WAVE_MAX_NPROD = 4096; // beyond it only the workgroup kernel (long B rows) takes a row
 constexpr int SYM_WIN0 = 0, SYM_HASH0 = 24, SYM_GLOBAL0 = SYM_HASH0 + 4 * HASH_TIERS, SYM_NBINS = SYM_GLOBAL0 + 4;
 constexpr int NUM_WIN0 = 0, NUM_HASH0 = 96, NUM_GLOBAL = NUM_HASH0 + 4 * HASH_TIERS, NUM_GRP0 = NUM_GLOBAL + 1,
               NUM_NBINS = NUM_GRP0 + 24;
@@ -38,7 +41,7 @@ __host__ __device__ inline uint32_t group_max_rows(uint64_t len_a) { return len_
 struct ClassParams {
   uint32_t win_max_span;   // window path allowed up to this column span (<= 65536)
   uint32_t win_ratio;      // ... and only if span <= win_ratio * nprod
-  uint32_t hash_max_nprod; // LDS hash symbolic up to this many products (<= 4096)
+  uint32_t hash_max_nprod; // LDS hash symbolic up to this many products (<= 8192)
   uint32_t g_thresh0, g_thresh1, g_thresh2; // mean B-row length thresholds for 8/16/32 lanes
   uint32_t short_max_nprod; // rows of the hash path with at most this many products take the short-row kernels (0: none)
 };
@@ -71,7 +74,7 @@ __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, ui
     uint32_t t = ceil_log2_u32(span < 2048u ? 2048u : span) - 11u;
     return SYM_WIN0 + t * 4 + g;
   }
-  if (nprod <= p.hash_max_nprod) {
+  if (nprod <= p.hash_max_nprod && (nprod <= HASH_WAVE_MAX_NPROD || g == 3u)) {
     uint32_t t = ceil_log2_u32(nprod < 64u ? 64u : (uint32_t)nprod) - 6u; // nprod <= 64 << t
     if (nprod <= p.short_max_nprod && nprod <= SH_MAX_NPROD && len_a <= SH_MAX_ALEN) return SYM_HASH0 + t * 4;
     return SYM_HASH0 + t * 4 + (g ? g : 1u);

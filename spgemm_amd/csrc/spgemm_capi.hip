@@ -423,7 +423,7 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
   raise_lds_limit(k_sym_big);
-  raise_lds_limit(k_sym_hash_wg<256>); raise_lds_limit(k_sym_hash_wg<512>);
+  raise_lds_limit(k_sym_hash_wg<256>); raise_lds_limit(k_sym_hash_wg<512>); raise_lds_limit(k_sym_hash_wg<1024>);
   raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
   raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
   raise_lds_limit(k_num_short<4, true>); raise_lds_limit(k_num_short<SH_STEPS, true>);
@@ -458,7 +458,7 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
   ctx->device = device;
   ctx->cp.win_max_span = 65536;
   ctx->cp.win_ratio = 128;
-  ctx->cp.hash_max_nprod = 4096;
+  ctx->cp.hash_max_nprod = 8192;
   ctx->cp.g_thresh0 = 6;
   ctx->cp.g_thresh1 = 12;
   ctx->cp.g_thresh2 = 24;
@@ -640,7 +640,7 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "window_ratio") {
     ctx->cp.win_ratio = (uint32_t)value;
   } else if (n == "hash_max_nprod") {
-    if (value > 4096) return fail(SPGEMM_ERR_INVALID, "hash_max_nprod is at most 4096");
+    if (value > 8192) return fail(SPGEMM_ERR_INVALID, "hash_max_nprod is at most 8192");
     ctx->cp.hash_max_nprod = (uint32_t)value;
   } else if (n == "g_thresh0") {
     ctx->cp.g_thresh0 = (uint32_t)value;
@@ -740,8 +740,10 @@ static int validate_device(spgemm_ctx *ctx, const spgemm_mat *m) {
 }
 
 static int check_dims(uint64_t rows, uint64_t cols) {
-  if (rows >= 0xFFFFFFFFull || cols >= 0xFFFFFFFFull)
-    return fail(SPGEMM_ERR_UNSUPPORTED, "rows and cols must be below 2^32 - 1 (row/column ids are 32 bit)");
+  // rows: the one-thread-per-row kernels round the grid up to whole workgroups of 256 and keep the
+  // thread id in 32 bits
+  if (rows >= 0xFFFFFF00ull || cols >= 0xFFFFFFFFull)
+    return fail(SPGEMM_ERR_UNSUPPORTED, "rows must be below 2^32 - 256 and cols below 2^32 - 1 (row/column ids are 32 bit)");
   return SPGEMM_OK;
 }
 
@@ -1186,9 +1188,12 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       size_t region = ((size_t)8 << log2s) + (flat ? FLAT_BYTES : 0);
       uint32_t wpb = pick_wpb(region);
       st.rows_hash += cnt;
-      if (!flat && log2s >= 12) { // 32 KiB of table and more: the four wavefronts of a workgroup share it
-        TRY(prof_begin(ctx, 0, 1, log2s >= 13 ? 512 : 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
-        if (log2s >= 13)
+      if ((!flat && log2s >= 12) || log2s >= 14) { // 32 KiB of table and more: the wavefronts of a workgroup share it
+        TRY(prof_begin(ctx, 0, 1, log2s >= 14 ? 1024 : log2s >= 13 ? 512 : 256, cnt, log2s, 0, (size_t)8 << log2s, rows_bin));
+        if (log2s >= 14) // 128 KiB: one workgroup of 16 wavefronts per CU
+          hipLaunchKernelGGL(k_sym_hash_wg<1024>, dim3(cnt), dim3(1024), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB,
+                             rm, log2s);
+        else if (log2s >= 13)
           hipLaunchKernelGGL(k_sym_hash_wg<512>, dim3(cnt), dim3(512), (size_t)8 << log2s, ctx->stream, rows_bin, cnt, cA, cB,
                              rm, log2s);
         else

@@ -10,7 +10,7 @@ from spgemm_amd import capi, hostcsr
 
 pytestmark = pytest.mark.gpu
 
-DEFAULTS = {"window_max_span": 65536, "window_ratio": 128, "hash_max_nprod": 4096, "big_win_words": 32768,
+DEFAULTS = {"window_max_span": 65536, "window_ratio": 128, "hash_max_nprod": 8192, "big_win_words": 32768,
             "slice_blocks": 0, "hash_num_slice": 1024, "row_groups": 1, "flat_walk": 1, "big_rows": 1,
             "g_thresh2": 24, "lane_order_adds": 1, "slice_queues": 1, "slice_packed": 0, "short_packed": 2, "grp_compact": 2, "short_key32": 1, "analyze_lanes": 0, "walk_tail": 2}
 

@@ -20,6 +20,9 @@ def ctx():
     c.close()
 
 
+HASH_MAX_NPROD_DEFAULT = 8192  # the library's default of that option
+
+
 def to_ocsr(h):
     return orc.OCsr(h.rows, h.cols, h.row_ptr, h.col_idx, h.val)
 
@@ -123,7 +126,7 @@ def test_rmat_scale17_natural_big_rows(ctx):
     through the big-row kernels (bitmap windows; lists, slices and hub rows in the numeric pass)."""
     A = hostcsr.rmat(17, 8, seed=1)
     C, st = check(ctx, A, A)
-    assert st["rows_global"] > 10000 and C.nnz == 183630319
+    assert st["rows_global"] > 8000 and C.nnz == 183630319  # 9,197 rows with the hash taking up to 8,192 products
 
 
 def test_rmat_forced_hash_and_global(ctx):
@@ -136,6 +139,23 @@ def test_rmat_forced_hash_and_global(ctx):
         ctx.set_option("window_max_span", 65536)
 
 
+def test_rmat_workgroup_hash_tier_of_8192_products(ctx):
+    """Rows of 4,097..8,192 products whose B rows are long take the largest hash tier: one table of
+    128 KiB per workgroup of 1,024 threads."""
+    A = hostcsr.rmat(15, 8, seed=4)
+    ctx.set_option("window_max_span", 0)
+    ctx.set_option("hash_max_nprod", 8192)
+    ctx.set_option("profile_launches", 1)
+    try:
+        _, st = check(ctx, A, A)
+        assert any(l["phase"] == "symbolic" and l["path"] == "hash" and l["lanes"] == 1024 for l in ctx.launches())
+        assert st["rows_global"] > 0
+    finally:
+        ctx.set_option("window_max_span", 65536)
+        ctx.set_option("hash_max_nprod", HASH_MAX_NPROD_DEFAULT)
+        ctx.set_option("profile_launches", 0)
+
+
 def test_rmat_forced_global_only(ctx):
     A = hostcsr.rmat(10, 8, seed=3)
     ctx.set_option("window_max_span", 0)
@@ -145,7 +165,7 @@ def test_rmat_forced_global_only(ctx):
         assert st["rows_global"] > 0 and st["rows_hash"] == 0
     finally:
         ctx.set_option("window_max_span", 65536)
-        ctx.set_option("hash_max_nprod", 4096)
+        ctx.set_option("hash_max_nprod", HASH_MAX_NPROD_DEFAULT)
 
 
 def test_shell_like_small(ctx):
@@ -304,7 +324,7 @@ def test_big_rows_slices_and_windows(ctx, win_words):
         assert st["rows_global"] > 1000
     finally:
         ctx.set_option("window_max_span", 65536)
-        ctx.set_option("hash_max_nprod", 4096)
+        ctx.set_option("hash_max_nprod", HASH_MAX_NPROD_DEFAULT)
         ctx.set_option("big_win_words", 32768)
 
 
