@@ -89,7 +89,9 @@ int spgemm_ctx_device(const spgemm_ctx *ctx, int *device);
 int spgemm_set_stream(spgemm_ctx *ctx, void *hip_stream);
 int spgemm_synchronize(spgemm_ctx *ctx);
 /* Tunables, by name; unknown names are an error.
- *   window_max_span, window_ratio, hash_max_nprod   row binning (window / LDS hash / big rows)
+ *   window_max_span, window_ratio, hash_max_nprod   row binning (window / LDS hash / big rows);
+ *                                                   hash_max_nprod <= 8192 (default 8192: rows of more
+ *                                                   than 4096 products only where B's rows are long)
  *   short_max_nprod                                 rows outside the window path with at most this many
  *                                                   products (<= 512) and at most 64 A entries take the
  *                                                   short-row kernels (count-only symbolic pass, numeric
