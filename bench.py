@@ -185,8 +185,7 @@ def run_single(args):
         C = ctx.multiply(dA, dA)
         C.free()
         st = ctx.stats()
-        ls = ctx.launches()
-        ms = np.array([l["ms"] for l in ls])
+        ms = ctx.launch_ms()
         per_launch_ms = ms if per_launch_ms is None else per_launch_ms + ms
         for k in ("ms_analyze", "ms_symbolic", "ms_scan", "ms_numeric", "ms_compact", "ms_total"):
             phase_ms[k] = phase_ms.get(k, 0.0) + st[k]

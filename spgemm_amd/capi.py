@@ -71,6 +71,12 @@ class LaunchInfo(ctypes.Structure):
         return d
 
 
+# the same layout for numpy (a C struct of natural alignment: no padding between these fields)
+_LAUNCH_DTYPE = np.dtype([("phase", "<u4"), ("path", "<u4"), ("lanes", "<u4"), ("rows", "<u4"), ("param0", "<u4"),
+                          ("param1", "<u4"), ("ms", "<f4"), ("lds_bytes", "<u4"), ("nnz_a", "<u8"), ("nprod", "<u8"),
+                          ("nnz_c", "<u8")])
+assert _LAUNCH_DTYPE.itemsize == ctypes.sizeof(LaunchInfo)
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -347,6 +353,16 @@ class Context:
         arr = (LaunchInfo * max(n.value, 1))()
         _check(load().spgemm_get_launches(self.handle, arr, n.value, ctypes.byref(n)))
         return [arr[i].as_dict() for i in range(n.value)]
+
+    def launch_ms(self) -> np.ndarray:
+        """Only the durations of launches(), in the same order, without building a record per launch
+        (for a timing loop that adds them up step by step)."""
+        n = ctypes.c_int(0)
+        _check(load().spgemm_get_launches(self.handle, None, 0, ctypes.byref(n)))
+        arr = (LaunchInfo * max(n.value, 1))()
+        _check(load().spgemm_get_launches(self.handle, arr, n.value, ctypes.byref(n)))
+        rec = np.frombuffer(arr, dtype=_LAUNCH_DTYPE, count=n.value)
+        return rec["ms"].astype(np.float64)
 
     # -- bitmap / partition / shuffle ------------------------------------------------------------
     def shuffle_iterative(self, C: DeviceCsr, iterations: int):
