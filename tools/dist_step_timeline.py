@@ -1,9 +1,9 @@
 """Timeline of the last distributed step in a rocprofv3 kernel trace: python tools/dist_step_timeline.py <trace.csv>.
-A step starts at the kernel named by the second argument (default: the first kernel of the exchange)."""
+A step starts at the kernel named by the second argument (default: the row-info kernel, the first of the multiply that follows the exchange)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = sys.argv[2] if len(sys.argv) > 2 else "k_section_bitmap"
+first = sys.argv[2] if len(sys.argv) > 2 else "k_b_rowinfo"
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 lo, hi = starts[-2], starts[-1]
 t0 = int(rows[lo]["Start_Timestamp"])
