@@ -402,20 +402,27 @@ __global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *partial, uint32_t
 }
 
 // The whole scan in one workgroup, for inputs of up to SCAN_SMALL_MAX items (the block histograms of
-// a partition, the rows of a small matrix): one launch instead of two.  Every thread owns a
-// contiguous span.
+// a partition, the rows of a small matrix): one launch instead of two.  Every thread owns 16
+// consecutive items and has their loads in flight together (a loop over a span of the thread's own
+// waited for every load in turn: 13 us for 11,000 items).
 constexpr uint32_t SCAN_SMALL_MAX = 16384;
 __global__ void __launch_bounds__(1024)
     k_scan_small(const uint32_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ out) {
+  static_assert(SCAN_SMALL_MAX == 1024u * 16u, "16 items per thread");
   __shared__ uint64_t s_wave[16];
-  const uint32_t per = (n + 1023u) >> 10, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+  const uint32_t lo = threadIdx.x * 16u;
+  uint32_t v[16];
+#pragma unroll
+  for (uint32_t i = 0; i < 16u; ++i) v[i] = lo + i < n ? in[lo + i] : 0u;
   uint64_t s = 0;
-  for (uint32_t i = lo; i < hi; ++i) s += in[i];
+#pragma unroll
+  for (uint32_t i = 0; i < 16u; ++i) s += v[i];
   uint64_t tot;
   uint64_t ex = block_excl_scan64(s, s_wave, &tot);
-  for (uint32_t i = lo; i < hi; ++i) {
-    out[i] = ex;
-    ex += in[i];
+#pragma unroll
+  for (uint32_t i = 0; i < 16u; ++i) {
+    if (lo + i < n) out[lo + i] = ex;
+    ex += v[i];
   }
   if (threadIdx.x == 0) out[n] = tot;
 }
