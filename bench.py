@@ -53,33 +53,51 @@ def make_workload(args):
     return A, name
 
 
-def measured_traffic(workload, kernel):
-    """(HBM bytes per launch of `kernel`, file) from the committed PMC profile of this workload
-    (profiles/*_traffic_<workload>.json, made by tools/prof_all.sh + tools/make_traffic.py: separate
-    rocprofv3 --pmc passes of this same command, read side rebuilt from the per-size request counters
-    because FETCH_SIZE tallies 128-B requests at 64 B on gfx950).  Counters cannot be read from
-    inside the run, so the figure is the one of the last profiled build; (None, None) when no profile
-    is committed for this workload and kernel."""
+def csrc_digest():
+    """SHA-1 over the kernel and C-ABI sources: names the build a committed profile was made from."""
     import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "spgemm_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "spgemm_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` and the SQ counters of that launch, from the committed PMC
+    profile of this workload (profiles/*_traffic_<workload>.json, made by tools/prof_all.sh +
+    tools/make_traffic.py: separate rocprofv3 --pmc passes of this same command, the read side
+    rebuilt from the per-size request counters because FETCH_SIZE tallies 128-B requests at 64 B on
+    gfx950).  Counters cannot be read from inside the run, so the figures are those of the last
+    profiled build: they are returned only when that profile was made from THESE sources (the
+    profile records a digest of spgemm_amd/csrc) and holds this kernel; else everything is None and
+    `stale` says why."""
+    import glob
+    out = {"traffic": None, "file": None, "sq": None, "stale": None}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_traffic_{workload}.json")))
     if not files:
-        return None, None
-    kernels = json.load(open(files[-1]))["kernels"]
+        out["stale"] = "no profile committed for this workload"
+        return out
+    prof = json.load(open(files[-1]))
+    out["file"] = os.path.relpath(files[-1], ROOT)
+    if prof.get("csrc_sha1") != csrc_digest():
+        out["stale"] = "the committed profile was made from other kernel sources than the ones timed here"
+        return out
     # template arguments differ between instantiations of one kernel: the largest launch counts
-    match = [v for name, v in kernels.items() if name == kernel or name.startswith(kernel + "<")]
+    match = [v for name, v in prof["kernels"].items() if name == kernel or name.startswith(kernel + "<")]
     if not match:
-        return None, None
+        out["stale"] = "the committed profile holds no launch of this kernel"
+        return out
     best = max(match, key=lambda m: m["hbm_bytes"])
-    measured_traffic.counters = best.get("sq")
-    return best["hbm_bytes"], os.path.relpath(files[-1], ROOT)
-
-
-measured_traffic.counters = None
+    out["traffic"], out["sq"] = best["hbm_bytes"], best.get("sq")
+    return out
 
 
 def issue_bounds(sq, kernel_ms, n_cu=256, clock_ghz=2.4):
-    """Lower bounds on a kernel's time from what it issues, out of the committed SQ counters of the
-    same launch: every vector instruction holds one of the 4 * n_cu SIMDs for 4 cycles, every LDS-array
+    """Lower bounds on a kernel's time from what it issues, out of the SQ counters of the same
+    launch: every vector instruction holds one of the 4 * n_cu SIMDs for 4 cycles, every LDS-array
     cycle one of the n_cu LDS units.  The clock is the peak one, so the bounds are optimistic."""
     if not sq:
         return None
@@ -162,26 +180,24 @@ def cpu_baseline(A, target_seconds=10.0):
                                           f"fill pass with a dense accumulator per thread"}}
 
 
-def run_single(args):
-    import torch  # device selection / presence check only
-    from spgemm_amd import capi
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
-    A, name = make_workload(args)
-    ctx = capi.Context(0)
+def measure_workload(ctx, A, workload_key, steps, warmup, opts=()):
+    """Times `steps` multiplies C = A * A on the context (after `warmup` untimed ones, A resident in
+    HBM) and returns (ms per step, stats, launches with their mean durations, roofline of the
+    dominant numeric launch, whole-multiply figures)."""
+    import torch
     dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
     ctx.set_option("profile_launches", 1)
-    for o in args.opt:
+    for o in opts:
         opt_name, opt_value = o.split("=")
         ctx.set_option(opt_name, int(opt_value))
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ctx.multiply(dA, dA).free()
     ctx.synchronize()
     torch.cuda.synchronize()
     per_launch_ms = None
     phase_ms = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         C = ctx.multiply(dA, dA)
         C.free()
         st = ctx.stats()
@@ -192,15 +208,17 @@ def run_single(args):
     ctx.synchronize()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    ms_per_step = (t1 - t0) * 1e3 / args.steps
-    per_launch_ms = per_launch_ms / args.steps
-    phase_ms = {k: v / args.steps for k, v in phase_ms.items()}
+    ms_per_step = (t1 - t0) * 1e3 / steps
+    per_launch_ms = per_launch_ms / steps
+    phase_ms = {k: v / steps for k, v in phase_ms.items()}
 
     # one untimed multiply that also sums the rows of every launch (bytes per launch)
     ctx.set_option("profile_launches", 2)
     ctx.multiply(dA, dA).free()
     launches = ctx.launches()
     st = ctx.stats()
+    ctx.set_option("profile_launches", 0)
+    dA.free()
     for l, ms in zip(launches, per_launch_ms):
         l["ms"] = float(ms)
     num = [l for l in launches if l["phase"] == "numeric"]
@@ -211,52 +229,90 @@ def run_single(args):
         b = algorithmic_bytes(dom["nnz_a"], dom["nprod"], dom["nnz_c"], dom["rows"])
         bc = compulsory_bytes(dom["nnz_a"], dom["nnz_c"], dom["rows"])
         sec = dom["ms"] * 1e-3
-        achieved = b / sec / 1e9
+        achieved = bc / sec / 1e9
         kname = kernel_name(dom)
-        traffic, traffic_file = measured_traffic(args.workload, kname)
+        prof = measured_traffic(workload_key, kname)
+        traffic = prof["traffic"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": kname, "kernel_ms": dom["ms"],
-                    "kernel_rows": dom["rows"], "kernel_algorithmic_bytes": b,
-                    "kernel_compulsory_bytes": bc, "frac_compulsory": bc / sec / 1e9 / HBM_PEAK_GBS,
+                    "basis": "compulsory bytes of the launch's rows (their A entries and as many B entries read once, "
+                             "their C entries written once, the row pointers) / kernel time: no kernel moves less, so "
+                             "frac <= 1 by construction",
+                    "kernel": kname, "kernel_ms": dom["ms"], "kernel_rows": dom["rows"],
+                    "kernel_compulsory_bytes": bc, "kernel_algorithmic_bytes": b,
+                    "frac_model_no_reuse": b / sec / 1e9 / HBM_PEAK_GBS,
+                    "model_no_reuse_note": "algorithmic bytes (12 B per product: every product's B entry from memory, no "
+                                           "reuse of B rows) / kernel time / peak: the traffic MODEL of row-wise Gustavson, "
+                                           "not a bound - above 1 where neighbouring rows share B rows in L2 / Infinity Cache",
                     "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
-                    "traffic_source": traffic_file,
-                    "note": "achieved = algorithmic bytes (no reuse of B rows) / kernel time: a model figure, "
-                            "above what HBM moves when B rows are re-read from L2 / Infinity Cache"}
+                    "traffic_source": prof["file"], "traffic_stale": prof["stale"]}
+        bounds = {"hbm_compulsory": bc / (HBM_PEAK_GBS * 1e9) / sec}
         if traffic:
             hbm_rate = traffic / sec / 1e9
-            roofline.update({"traffic_over_algorithmic": traffic / b, "hbm_rate_GBs": hbm_rate,
-                             "hbm_rate_frac_of_peak": hbm_rate / HBM_PEAK_GBS,
+            roofline.update({"traffic_over_algorithmic": traffic / b, "traffic_over_compulsory": traffic / bc,
+                             "hbm_rate_GBs": hbm_rate, "hbm_rate_frac_of_peak": hbm_rate / HBM_PEAK_GBS,
                              "limited_by": ("hbm" if copy_gbs and hbm_rate > 0.6 * copy_gbs else
                                             "instruction issue and LDS, not HBM (measured HBM rate well below the copy rate)")})
-            ib = issue_bounds(measured_traffic.counters, dom["ms"])
+            bounds["hbm_measured_traffic"] = hbm_rate / HBM_PEAK_GBS
+            ib = issue_bounds(prof["sq"], dom["ms"])
             if ib:
                 roofline["issue_bound"] = ib
+                bounds["lds_array"] = min(ib["lds_frac_of_kernel_time"], 1.0)
+                bounds["valu_issue"] = min(ib["valu_frac_of_kernel_time"], 1.0)
+        tight = max(bounds, key=bounds.get)
+        roofline["bounds"] = {"frac_of_each": bounds, "tightest": tight, "frac_of_tightest": bounds[tight],
+                              "note": "each entry = (time that bound alone would need) / kernel time, all <= 1; the LDS "
+                                      "and issue bounds exist only beside a profile of these very sources"}
     b_all = st["bytes_algorithmic"]
     bc_all = compulsory_bytes(st["nnz_a"], st["nnz_c"], st["rows_a"])
     sec_all = ms_per_step * 1e-3
-    gflops = 2.0 * st["nprod"] / sec_all / 1e9
+    whole = {"algorithmic_bytes": b_all, "compulsory_bytes": bc_all,
+             "compulsory_frac_of_hbm_peak": bc_all / sec_all / 1e9 / HBM_PEAK_GBS,
+             "frac_model_no_reuse": b_all / sec_all / 1e9 / HBM_PEAK_GBS,
+             "model_no_reuse_GBs": b_all / sec_all / 1e9,
+             "model_no_reuse_over_measured_copy": b_all / sec_all / 1e9 / copy_gbs if copy_gbs else None,
+             "measured_copy_GBs": copy_gbs, "phase_ms": phase_ms}
+    return ms_per_step, st, launches, roofline, whole
+
+
+def run_single(args):
+    import torch  # device selection / presence check only
+    from spgemm_amd import capi, hostcsr
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    A, name = make_workload(args)
+    ctx = capi.Context(0)
+    ms_per_step, st, launches, roofline, whole = measure_workload(ctx, A, args.workload, args.steps, args.warmup, args.opt)
+    gflops = 2.0 * st["nprod"] / (ms_per_step * 1e-3) / 1e9
     out = {
         "metric": "SpGEMM GFLOP/s (useful flops, 2*nprod/t) C=A*A fp64",
         "value": gflops, "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic" if args.workload != "mtx" else "file",
         "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": st["nprod"], "nnz_c": st["nnz_c"],
-                   "impl": "baseline", "parallelism": "1 GPU"},
+                   "impl": "baseline", "parallelism": "1 GPU",
+                   "stand_in": "synthetic matrix of the named SuiteSparse matrix's order and row length; the real file "
+                               "(not fetchable here) runs through --workload mtx" if args.workload in ("shell", "diel") else None},
         "roofline": roofline,
-        "whole_multiply": {"algorithmic_bytes": b_all, "achieved_GBs": b_all / sec_all / 1e9,
-                           "frac_of_hbm_peak": b_all / sec_all / 1e9 / HBM_PEAK_GBS,
-                           "frac_of_measured_copy": b_all / sec_all / 1e9 / copy_gbs if copy_gbs else None,
-                           "compulsory_bytes": bc_all,
-                           "compulsory_frac_of_hbm_peak": bc_all / sec_all / 1e9 / HBM_PEAK_GBS,
-                           "measured_copy_GBs": copy_gbs,
-                           "phase_ms": phase_ms},
+        "whole_multiply": whole,
         "launches": [{k: l[k] for k in ("phase", "path", "lanes", "rows", "ms", "lds_bytes", "nprod", "nnz_c")}
                      for l in launches],
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A)
-    dA.free()
+    # the second workload the target names: R-MAT scale 22 (edge factor 4), a bounded number of steps
+    if args.workload == "shell" and not args.no_also:
+        del A
+        R = hostcsr.rmat(22, 4, seed=1)
+        k = max(1, min(args.steps, 5))
+        ms2, st2, l2, roof2, whole2 = measure_workload(ctx, R, "rmat", k, 1, args.opt)
+        out["also"] = [{
+            "config": {"workload": "R-MAT scale 22, edge factor 4, C=A*A", "rows": R.rows, "nnz_a": R.nnz,
+                       "nprod": st2["nprod"], "nnz_c": st2["nnz_c"], "impl": "baseline", "parallelism": "1 GPU"},
+            "steps": k, "warmup": 1, "ms_per_step": ms2, "value": 2.0 * st2["nprod"] / (ms2 * 1e-3) / 1e9, "unit": "GFLOP/s",
+            "roofline": roof2, "whole_multiply": whole2,
+            "launches": [{kk: l[kk] for kk in ("phase", "path", "lanes", "rows", "ms", "lds_bytes", "nprod", "nnz_c")} for l in l2],
+        }]
     ctx.close()
     print(json.dumps(out))
 
@@ -280,6 +336,8 @@ def main():
                     help="distributed variant: > 1 cuts a rank's rows into that many blocks and overlaps the "
                          "exchange of the next block with the multiply of the current one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default run (shell) only: leave out the block of the R-MAT scale-22 workload")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (spgemm_set_option), e.g. --opt row_groups=0")
     ap.add_argument("--dist", action="store_true",

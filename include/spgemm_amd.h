@@ -80,6 +80,10 @@ int spgemm_device_count(int *count);
 /* ---- context: the per-rank state the reference keeps in a mults::MatrixMultiplication
  *      object (include/mults.hpp:17-33) ----------------------------------------------------- */
 int spgemm_create(int device, spgemm_ctx **ctx);
+/* Waits for the context's stream, then releases everything the context holds, INCLUDING every
+ * matrix handle that was made on it and not freed (spgemm_mat_from_host, _wrap_device, _multiply,
+ * _select, _relabel_columns): such handles are dead afterwards and must not be used or freed.  The
+ * reference's operator object owns its operands and result the same way (include/mults.hpp:35-50). */
 int spgemm_destroy(spgemm_ctx *ctx);
 int spgemm_ctx_device(const spgemm_ctx *ctx, int *device);
 /* Run on a caller-owned hipStream_t (e.g. the framework's current stream).  NULL restores the
@@ -141,7 +145,12 @@ int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t value);
 
 /* What spgemm_create found out about the context's device (no counterpart in the reference).
  *   "lane_order_probe"   1 when one LDS fp64 add applied lanes that share an address in ascending lane
- *                        order in every trial of the probe (the flat walks then add with one instruction)
+ *                        order in every trial of the probe (run once per device and process: 16,384
+ *                        workgroup trials, four wavefronts adding at once into one table, strides of
+ *                        1..64 entries, powers of two included).  The flat walks then add 64 products
+ *                        with one instruction, and their bit parity with the CPU loop RESTS ON THIS
+ *                        PROBE: the order is not documented by the hardware manuals.  Option
+ *                        lane_order_adds = 0 takes the order-independent path instead.
  *   "cu_count"           compute units of the device */
 int spgemm_device_property(const spgemm_ctx *ctx, const char *name, int64_t *value);
 
@@ -179,6 +188,10 @@ int spgemm_mat_rows_to_host(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t row0,
  * (scripts/compare_matrices.py:18-50 compares the values only). */
 int spgemm_mat_check(spgemm_ctx *ctx, const spgemm_mat *m, uint64_t *rows_not_increasing,
                      uint64_t *zero_values);
+/* Frees a handle made on THIS context (its device arrays too, unless they were wrapped).  NULL is
+ * a no-op; a handle that this context does not know (made on another context, or freed already)
+ * is refused with SPGEMM_ERR_INVALID and left alone.  Handles still alive when the context is
+ * destroyed are freed by spgemm_destroy. */
 int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m);
 
 /* ---- the multiply: replaces reset() + the local multiply inside gemm()
@@ -303,8 +316,9 @@ int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
  * arguments, same result, but no hipMalloc / hipFree or allocating library routine is called.  It
  * has no counterpart in the reference.  Its scratch (row lengths and scan partials, 16 MiB) is a
  * static device array of the library: at most 4,194,304 rows (SPGEMM_ERR_UNSUPPORTED beyond).
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (from different
- * contexts or streams) race; calls on one context are ordered by its stream. */
+ * Every call on a GPU shares that GPU's array.  Calls made through this library in one process are
+ * ordered on the device (a call from another stream or context waits for the previous call's
+ * kernels); calls from different PROCESSES on one GPU each have their own copy of the array. */
 int spgemm_assemble_row_ptr_noalloc(spgemm_ctx *ctx, uint64_t rows, uint32_t n_sections,
                                     const uint64_t *bitmap_words, const uint32_t *d_row_len_concat,
                                     uint64_t n_row_len, uint64_t *d_row_ptr_out, uint64_t *nnz_out);

@@ -35,10 +35,14 @@
  *     reference is built with g++ -O3 for baseline x86-64, which has no fused
  *     multiply-add); this file must be built with -ffp-contract=off.
  */
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -520,4 +524,32 @@ int oracle_max_threads(void) {
 #else
   return 1;
 #endif
+}
+
+/*
+ * Test-run diagnostics (no counterpart in the reference): a SIGABRT handler that writes the NATIVE
+ * call stack of the aborting thread to standard error before the handler that was installed
+ * before it runs (Python's faulthandler shows Python frames only, and of every thread alike, so an
+ * abort raised inside a C library or by a runtime thread cannot be told apart from the log).
+ */
+static struct sigaction abort_prev;
+static void abort_trace_handler(int sig) {
+  static const char head[] = "\n--- SIGABRT: native stack of the aborting thread ---\n";
+  void *frames[64];
+  ssize_t ignored = write(2, head, sizeof(head) - 1);
+  (void)ignored;
+  int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  sigaction(SIGABRT, &abort_prev, NULL); /* then whoever was there before (faulthandler, or the default) */
+  raise(sig);
+}
+int oracle_install_abort_trace(void) {
+  struct sigaction sa;
+  void *warm[4];
+  backtrace(warm, 4); /* loads libgcc's unwinder now, not inside the handler */
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_handler = abort_trace_handler;
+  sigemptyset(&sa.sa_mask);
+  sa.sa_flags = SA_NODEFER;
+  return sigaction(SIGABRT, &sa, &abort_prev);
 }

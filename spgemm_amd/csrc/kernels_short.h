@@ -27,11 +27,15 @@ struct ColMap {
   const uint4 *__restrict__ prec; // B rows as padded {column, 0, value} records (k_prec_fill), or null
   const uint32_t *__restrict__ pcol; // the columns of those records alone, at the same positions, or null
 };
-__device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
+// value of the map at column c, given the prefix counts lo, hi at the two ends of c's bin
+__device__ __forceinline__ double colmap_interp(const ColMap &cm, uint32_t c, double lo, double hi) {
   const uint32_t b = c >> cm.shift;
-  const double lo = cm.cdf[b], hi = cm.cdf[b + 1];
   const double frac = (double)(c - (b << cm.shift)) * cm.inv_width;
   return lo + (hi - lo) * frac;
+}
+__device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
+  const uint32_t b = c >> cm.shift;
+  return colmap_interp(cm, c, cm.cdf[b], cm.cdf[b + 1]);
 }
 
 // inclusive max-scan over the 64 lanes (0 is the identity)
@@ -307,9 +311,9 @@ __global__ void __launch_bounds__(256)
         *reinterpret_cast<ulonglong2 *>(&tab[j]) = make_ulonglong2(~0ull, ~0ull);
     }
     // the row's own column range stretched over the home slots
-    const double inv = cm.inv_width;
-    const double f_lo = cur.f[0] + (cur.f[1] - cur.f[0]) * ((double)(cur.cmin - ((cur.cmin >> cm.shift) << cm.shift)) * inv);
-    const double f_hi = cur.f[2] + (cur.f[3] - cur.f[2]) * ((double)(cur.cmax - ((cur.cmax >> cm.shift) << cm.shift)) * inv);
+    // (the same expression as colmap_eval, so that a product in column cmin maps to exactly f_lo)
+    const double f_lo = colmap_interp(cm, cur.cmin, cur.f[0], cur.f[1]);
+    const double f_hi = colmap_interp(cm, cur.cmax, cur.f[2], cur.f[3]);
     const double scale = (double)H / (f_hi - f_lo + 1.0);
     key_t x[STEPS];
     uint32_t h[STEPS];
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t q = (uint32_t)u * 64u + lane;
         prodv[q] = __dmul_rn(avs[cur.t[u]], cur.bv[u]);
         x[u] = ((key_t)cur.c[u] << cshift) | q;
-        h[u] = min(H - 1u, (uint32_t)((fc[u] - f_lo) * scale));
+        h[u] = min(H - 1u, (uint32_t)fmax(0.0, (fc[u] - f_lo) * scale)); // (never below zero: the map is monotone)
       }
     }
     // the row's values and A entries are used up: the next row is expanded now (its B entries are in

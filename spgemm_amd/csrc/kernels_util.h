@@ -157,11 +157,20 @@ __global__ void __launch_bounds__(256) k_report(ReportSegs r) {
 // ---- probe: order of the lanes of one LDS fp64 add that share an address -----------------------------
 // The flat walks add up to 64 products with ONE ds_add_f64 instruction and need the lanes that hit
 // the same accumulator to be applied in ascending lane order (the CPU's order of the products).
-// Each trial lets the 64 lanes of a wavefront add doubles of very different magnitude to a few
-// accumulators (1 .. 64 of them, at several strides, some lanes idle) and compares every
-// accumulator bit for bit with the sum taken lane by lane.  out[0] counts the differences.
+// Bit parity of those kernels with the CPU loop rests on this probe: the hardware's order is not
+// documented.  Each trial lets the 64 lanes of every wavefront of the workgroup add doubles of
+// very different magnitude to a few accumulators (1 .. 64 of them, some lanes idle) and compares
+// every accumulator bit for bit with the sum taken lane by lane.  The patterns are those of the
+// kernels that rely on the order: all wavefronts of the workgroup add at the same time into ONE
+// table of PROBE_SLOTS doubles (just under a CU's 160 KiB), their accumulators interleaved (wave w
+// owns the entries 4 * k + w), at strides of 1 .. 64 entries between a wave's accumulators, powers
+// of two included: every accumulator of a trial then falls into the same few banks.  out[0] counts
+// the differences.
+constexpr uint32_t PROBE_SLOTS = 19456, PROBE_LDS_BYTES = PROBE_SLOTS * 8u, PROBE_BLOCKS = 256, PROBE_TRIALS = 64;
+static_assert(63u * 64u * 4u + 3u < PROBE_SLOTS, "the largest stride keeps 64 accumulators of 4 wavefronts inside the table");
 __global__ void __launch_bounds__(256) k_probe_lane_order(uint32_t trials, unsigned long long *__restrict__ out) {
-  __shared__ double acc[4][1024];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *acc = reinterpret_cast<double *>(smem);
   __shared__ double xs[4][64];
   __shared__ uint32_t ps[4][64];
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -173,23 +182,25 @@ __global__ void __launch_bounds__(256) k_probe_lane_order(uint32_t trials, unsig
   for (uint32_t t = 0; t < trials; ++t) {
     const uint32_t cfg = blockIdx.x + t;
     const uint32_t nslots = 1u + (cfg * 7u) % 64u;
-    const uint32_t stride = (cfg & 1u) ? 1u + 2u * ((cfg >> 1) % 17u) : 1u; // odd: distinct slots stay distinct mod 1024
+    // strides 1, 2, 4, ... 64 (every accumulator in the same banks) and the odd ones in between
+    const uint32_t stride = (cfg & 1u) ? 1u << ((cfg >> 1) % 7u) : 1u + 2u * ((cfg >> 1) % 32u);
     const uint64_t h = mix(((uint64_t)blockIdx.x << 40) ^ ((uint64_t)w << 34) ^ ((uint64_t)t << 8) ^ lane);
     const uint32_t slot = (uint32_t)(h % nslots);
     double x = ldexp(1.0 + (double)((h >> 32) & 0xFFFFFu) / 1048576.0, (int)((h >> 20) % 60u) - 30);
     if (h & (1ull << 60)) x = -x;
     const bool active = (cfg & 2u) == 0 || (mix(h) % 3u) != 0;
-    for (uint32_t i = lane; i < 1024; i += 64) acc[w][i] = 0.0;
+    const uint32_t span = 64u * stride * 4u; // entries the four wavefronts' accumulators of this trial lie in
+    for (uint32_t i = threadIdx.x; i < span; i += 256) acc[i] = 0.0;
     xs[w][lane] = x;
     ps[w][lane] = active ? slot : 0xFFFFFFFFu;
     __syncthreads();
-    if (active) lds_add_f64(&acc[w][(slot * stride) & 1023u], x);
+    if (active) lds_add_f64(&acc[slot * stride * 4u + w], x);
     __syncthreads();
     if (lane < nslots) {
       double up = 0.0;
       for (int l = 0; l < 64; ++l)
         if (ps[w][l] == lane) up += xs[w][l];
-      if (__double_as_longlong(acc[w][(lane * stride) & 1023u]) != __double_as_longlong(up)) ++bad;
+      if (__double_as_longlong(acc[lane * stride * 4u + w]) != __double_as_longlong(up)) ++bad;
     }
     __syncthreads();
   }
@@ -205,10 +216,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// ---- streaming copy: what this GPU's HBM delivers to a plain 16-byte-per-lane copy ------------------------
+// ---- streaming copy: what this GPU's HBM delivers to a plain copy -----------------------------------------
+// Every lane has four 16-byte loads in flight before its first store; a workgroup moves tiles of
+// 16 KiB (four rows of 256 lanes x 16 bytes).
+constexpr uint32_t COPY_UNROLL = 4;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
-    k_stream_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+    k_stream_copy(const uint4 *__restrict__ src4, uint4 *__restrict__ dst4, uint64_t n16) {
+  const u32x4_t *__restrict__ src = reinterpret_cast<const u32x4_t *>(src4);
+  u32x4_t *__restrict__ dst = reinterpret_cast<u32x4_t *>(dst4);
+  const uint64_t tile = 256ull * COPY_UNROLL;
+  const uint64_t ntiles = n16 / tile;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t i = t * tile + threadIdx.x;
+    u32x4_t v[COPY_UNROLL];
+#pragma unroll
+    for (uint32_t u = 0; u < COPY_UNROLL; ++u) v[u] = __builtin_nontemporal_load(&src[i + 256ull * u]);
+#pragma unroll
+    for (uint32_t u = 0; u < COPY_UNROLL; ++u) __builtin_nontemporal_store(v[u], &dst[i + 256ull * u]);
+  }
+  for (uint64_t i = ntiles * tile + (uint64_t)blockIdx.x * 256ull + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256ull)
     dst[i] = src[i];
 }
 

@@ -10,10 +10,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <random>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 using namespace sg;
@@ -125,6 +127,7 @@ struct spgemm_ctx {
   unsigned char *noalloc_scratch = nullptr; // this device's copy of `scratch` (hipGetSymbolAddress)
   std::vector<Block> pool;  // freed output buffers, reused by later multiplies
   std::vector<Block> buffers; // live blocks handed out by spgemm_buffer_alloc
+  std::unordered_set<spgemm_mat *> live_mats; // every matrix handle made on this context and not yet freed
   size_t pool_bytes = 0;
   spgemm_stats stats;
   // per-launch profile (option "profile_launches")
@@ -166,6 +169,7 @@ struct spgemm_ctx {
 };
 
 static constexpr size_t PINNED_BYTES = 8192;
+static void release_mat(spgemm_ctx *ctx, spgemm_mat *m);
 static constexpr size_t POOL_LIMIT_BLOCKS = 16;
 
 // ---- scratch of the allocation-free entry point -----------------------------------------------------
@@ -178,6 +182,22 @@ static constexpr size_t NOALLOC_LEN_BYTES = ((NOALLOC_MAX_ROWS + 1) * 4 + 255) /
 static constexpr size_t NOALLOC_PARTIAL_BYTES =
     (((NOALLOC_MAX_ROWS + (uint64_t)SCAN_BLOCK * SCAN_ITEMS - 1) / ((uint64_t)SCAN_BLOCK * SCAN_ITEMS) + 2) * 8 + 255) / 256 * 256;
 static __device__ __align__(256) unsigned char scratch[NOALLOC_LEN_BYTES + NOALLOC_PARTIAL_BYTES];
+
+// ---- per-device state shared by the contexts of a process -----------------------------------------------
+// probe: result of k_probe_lane_order on the device (-1: not run yet); one launch and one host
+// round trip per device and process instead of per context.
+// scratch guard: every context of a GPU shares that GPU's copy of `scratch`.  The calls of one
+// context are ordered by its stream; a call from ANOTHER stream first waits (on the device, through
+// an event recorded behind the previous call) until that call's kernels are done with the array.
+struct DeviceShared {
+  std::mutex mu;
+  int probe = -1;
+  hipEvent_t scratch_done = nullptr; // recorded after the last user of `scratch` on this device
+  hipStream_t scratch_stream = nullptr;
+  bool scratch_used = false;
+};
+static constexpr int MAX_DEVICES = 64;
+static DeviceShared g_dev[MAX_DEVICES];
 
 // ---- helpers ------------------------------------------------------------------------------------
 static bool walk_tail(const spgemm_ctx *ctx, const spgemm_mat *B) {
@@ -427,6 +447,7 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
   raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
   raise_lds_limit(k_num_short<4, true>); raise_lds_limit(k_num_short<SH_STEPS, true>);
+  raise_lds_limit(k_probe_lane_order);
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -451,7 +472,7 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
   int n = 0;
   TRY(spgemm_device_count(&n));
   if (n <= 0) return fail(SPGEMM_ERR_HIP, "no HIP device is visible; this library has no CPU path");
-  if (device < 0 || device >= n) return fail(SPGEMM_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+  if (device < 0 || device >= n || device >= MAX_DEVICES) return fail(SPGEMM_ERR_INVALID, "device %d out of range (0..%d)", device, std::min(n, MAX_DEVICES) - 1);
   HIP_TRY(hipSetDevice(device));
   spgemm_ctx *ctx = new (std::nothrow) spgemm_ctx();
   if (!ctx) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
@@ -486,21 +507,36 @@ extern "C" int spgemm_create(int device, spgemm_ctx **out) {
       ctx->cu_count = cus;
   }
   // does one LDS fp64 add apply lanes that share an address in lane order?  (see k_probe_lane_order)
+  // Asked once per device and process; the event that guards the allocation-free entry point's
+  // scratch array is made at the same time.
   {
-    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(ctx->d_small);
-    unsigned long long bad = 1;
-    e = hipMemsetAsync(d_bad, 0, 8, ctx->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_probe_lane_order, dim3(128), dim3(256), 0, ctx->stream, 32u, d_bad);
-      e = hipGetLastError();
+    DeviceShared &ds = g_dev[device];
+    std::lock_guard<std::mutex> lock(ds.mu);
+    if (!ds.scratch_done) {
+      e = hipEventCreateWithFlags(&ds.scratch_done, hipEventDisableTiming);
+      if (e != hipSuccess) {
+        ds.scratch_done = nullptr;
+        (void)spgemm_destroy(ctx);
+        return fail(SPGEMM_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+      }
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-      (void)spgemm_destroy(ctx);
-      return fail(SPGEMM_ERR_HIP, "lane order probe failed: %s", hipGetErrorString(e));
+    if (ds.probe < 0) {
+      unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(ctx->d_small);
+      unsigned long long bad = 1;
+      e = hipMemsetAsync(d_bad, 0, 8, ctx->stream);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_lane_order, dim3(PROBE_BLOCKS), dim3(256), PROBE_LDS_BYTES, ctx->stream, PROBE_TRIALS, d_bad);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+        (void)spgemm_destroy(ctx);
+        return fail(SPGEMM_ERR_HIP, "lane order probe failed: %s", hipGetErrorString(e));
+      }
+      ds.probe = bad == 0 ? 1 : 0;
     }
-    ctx->hw_lane_order = bad == 0;
+    ctx->hw_lane_order = ds.probe == 1;
   }
   *out = ctx;
   return SPGEMM_OK;
@@ -510,6 +546,9 @@ extern "C" int spgemm_destroy(spgemm_ctx *ctx) {
   if (!ctx) return SPGEMM_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  // matrices never freed by the caller: their device arrays go back to the pool, which is emptied below
+  for (spgemm_mat *m : std::vector<spgemm_mat *>(ctx->live_mats.begin(), ctx->live_mats.end())) release_mat(ctx, m);
+  ctx->live_mats.clear();
   for (auto &b : ctx->pool) (void)hipFree(b.p);
   for (auto &b : ctx->buffers) (void)hipFree(b.p);
   if (ctx->arena.p) (void)hipFree(ctx->arena.p);
@@ -568,6 +607,7 @@ extern "C" int spgemm_internal_alloc_mat(spgemm_ctx *ctx, uint64_t rows, uint64_
     delete m;
     return rc;
   }
+  ctx->live_mats.insert(m);
   *out = m;
   return SPGEMM_OK;
 }
@@ -594,7 +634,7 @@ extern "C" int spgemm_internal_stream_copy_rate(spgemm_ctx *ctx, size_t bytes, i
   if (e == hipSuccess) e = hipMemsetAsync(dst, 0, bytes, ctx->stream);
   float best = 0.f;
   const uint64_t n16 = bytes / 16;
-  const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(n16, 256), (uint64_t)ctx->cu_count * 16);
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(n16, 256 * COPY_UNROLL), (uint64_t)ctx->cu_count * 32);
   for (int r = 0; r < reps + 1 && e == hipSuccess; ++r) { // first pass warms up
     e = hipEventRecord(e0, ctx->stream);
     hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4 *)src, (uint4 *)dst, n16);
@@ -762,6 +802,7 @@ extern "C" int spgemm_mat_from_host(spgemm_ctx *ctx, uint64_t rows, uint64_t col
   spgemm_mat *m = new (std::nothrow) spgemm_mat();
   if (!m) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
   m->rows = rows; m->cols = cols; m->nnz = nnz; m->owns = true; m->device = ctx->device;
+  ctx->live_mats.insert(m);
   int rc = pool_alloc(ctx, (rows + 1) * 8, (void **)&m->d_ptr, &m->bytes_ptr);
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 4, (void **)&m->d_col, &m->bytes_col);
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 8, (void **)&m->d_val, &m->bytes_val);
@@ -795,6 +836,7 @@ extern "C" int spgemm_mat_wrap_device(spgemm_ctx *ctx, uint64_t rows, uint64_t c
     int rc = validate_device(ctx, m);
     if (rc != SPGEMM_OK) { delete m; return rc; }
   }
+  ctx->live_mats.insert(m);
   *out = m;
   return SPGEMM_OK;
 }
@@ -899,30 +941,35 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
   return SPGEMM_OK;
 }
 
-extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
-  if (!m) return SPGEMM_OK;
-  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
-  (void)hipSetDevice(ctx->device);
+// Returns what the handle holds to the context's pool (or to nobody, for wrapped arrays) and deletes it.
+static void release_mat(spgemm_ctx *ctx, spgemm_mat *m) {
   if (ctx->plan.valid && (ctx->plan.A == m || ctx->plan.B == m)) ctx->plan.valid = false;
-  if (m->d_rowinfo) {
-    (void)hipStreamSynchronize(ctx->stream);
-    pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
-    if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
-    if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
-    if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
-    if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
-  }
-  if (m->d_rowlen) {
-    (void)hipStreamSynchronize(ctx->stream);
-    pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
-  }
+  if (m->d_rowinfo || m->d_rowlen || m->owns) (void)hipStreamSynchronize(ctx->stream);
+  if (m->d_rowinfo) pool_release(ctx, m->d_rowinfo, m->bytes_rowinfo);
+  if (m->d_colcdf) pool_release(ctx, m->d_colcdf, m->bytes_colcdf);
+  if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
+  if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
+  if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
+  if (m->d_rowlen) pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
   if (m->owns) {
-    (void)hipStreamSynchronize(ctx->stream);
     pool_release(ctx, m->d_ptr, m->bytes_ptr);
     pool_release(ctx, m->d_col, m->bytes_col);
     pool_release(ctx, m->d_val, m->bytes_val);
   }
   delete m;
+}
+
+extern "C" int spgemm_mat_free(spgemm_ctx *ctx, spgemm_mat *m) {
+  if (!m) return SPGEMM_OK;
+  if (!ctx) return fail(SPGEMM_ERR_INVALID, "ctx is NULL");
+  // only a handle that this context made and has not freed yet (a second free, or a free through
+  // another context, is refused instead of being followed)
+  auto it = ctx->live_mats.find(m);
+  if (it == ctx->live_mats.end())
+    return fail(SPGEMM_ERR_INVALID, "matrix handle does not belong to this context or was freed already");
+  ctx->live_mats.erase(it);
+  (void)hipSetDevice(ctx->device);
+  release_mat(ctx, m);
   return SPGEMM_OK;
 }
 
@@ -1568,6 +1615,7 @@ extern "C" int spgemm_multiply(spgemm_ctx *ctx, const spgemm_mat *A, const spgem
   spgemm_mat *C = new (std::nothrow) spgemm_mat();
   if (!C) return fail(SPGEMM_ERR_NOMEM, "host allocation failed");
   C->rows = A->rows; C->cols = B->cols; C->owns = true; C->device = ctx->device;
+  ctx->live_mats.insert(C);
   int rc = pool_alloc(ctx, (A->rows + 1) * 8, (void **)&C->d_ptr, &C->bytes_ptr);
   if (rc == SPGEMM_OK) rc = run_symbolic(ctx, A, B, C->d_ptr);
   uint64_t nnz_s = 0;
@@ -1781,6 +1829,7 @@ extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uin
   R->rows = n_out; R->cols = cols_out; R->owns = true; R->device = ctx->device;
   int rc = pool_alloc(ctx, (n_out + 1) * 8, (void **)&R->d_ptr, &R->bytes_ptr);
   if (rc != SPGEMM_OK) { delete R; return rc; }
+  ctx->live_mats.insert(R);
   const uint32_t *kr = keep_rows ? d_keep : nullptr, *cn = col_new_id ? d_new : nullptr;
   if (n_out) {
     hipLaunchKernelGGL(k_select_count, dim3(div_up_u64(n_out * 8, 256)), dim3(256), 0, ctx->stream, n_out, kr, M->d_ptr,
@@ -1979,6 +2028,7 @@ extern "C" int spgemm_assemble_row_ptr(spgemm_ctx *ctx, uint64_t rows, uint32_t 
                                        uint64_t *nnz_out) {
   if (!ctx || !bitmap_words || !d_row_ptr_out || n_sections == 0) return fail(SPGEMM_ERR_INVALID, "bad argument");
   if (rows / n_sections == 0) return fail(SPGEMM_ERR_INVALID, "rows / n_sections == 0");
+  if (n_row_len && !d_row_len_concat) return fail(SPGEMM_ERR_INVALID, "d_row_len_concat is NULL");
   TRY(check_dims(rows, 0));
   TRY(set_device(ctx));
   ctx->plan.valid = false;
@@ -2002,11 +2052,25 @@ extern "C" int spgemm_assemble_row_ptr_noalloc(spgemm_ctx *ctx, uint64_t rows, u
     return fail(SPGEMM_ERR_UNSUPPORTED, "spgemm_assemble_row_ptr_noalloc handles at most %llu rows (got %llu); use "
                 "spgemm_assemble_row_ptr", (unsigned long long)NOALLOC_MAX_ROWS, (unsigned long long)rows);
   if (!ctx->noalloc_scratch) return fail(SPGEMM_ERR_STATE, "internal: the scratch array has no device address");
+  if (n_row_len && !d_row_len_concat) return fail(SPGEMM_ERR_INVALID, "d_row_len_concat is NULL");
+  TRY(check_dims(rows, 0));
   TRY(set_device(ctx));
   uint32_t *d_len = reinterpret_cast<uint32_t *>(ctx->noalloc_scratch);
   uint64_t *partial = reinterpret_cast<uint64_t *>(ctx->noalloc_scratch + NOALLOC_LEN_BYTES);
-  return assemble_impl(ctx, rows, n_sections, bitmap_words, d_row_len_concat, n_row_len, d_row_ptr_out, nnz_out, d_len,
-                       partial);
+  // The scratch array is this GPU's, not this context's: a call that comes from another stream than
+  // the previous one waits, on the device, for the previous call's kernels (no allocation: the
+  // event was made when the first context of the device was).  With nnz_out the call returns after
+  // its own kernels have finished, so the lock also covers them.
+  DeviceShared &ds = g_dev[ctx->device];
+  std::lock_guard<std::mutex> lock(ds.mu);
+  if (ds.scratch_used && ds.scratch_stream != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, ds.scratch_done, 0));
+  const int rc = assemble_impl(ctx, rows, n_sections, bitmap_words, d_row_len_concat, n_row_len, d_row_ptr_out, nnz_out, d_len,
+                               partial);
+  // (recorded after a failed call too: part of its work may have been queued)
+  HIP_TRY(hipEventRecord(ds.scratch_done, ctx->stream));
+  ds.scratch_stream = ctx->stream;
+  ds.scratch_used = true;
+  return rc;
 }
 
 // ---- raw device buffers -------------------------------------------------------------------------------------

@@ -24,6 +24,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box)")
 
 
+def pytest_sessionstart(session):
+    # An abort (SIGABRT) of the test process names its origin: the checker library installs a handler
+    # that writes the native stack of the aborting thread to standard error, then hands over to
+    # Python's faulthandler (which pytest enabled before this hook).
+    try:
+        from oracle import oracle as orc
+        orc.lib().oracle_install_abort_trace()
+    except Exception as e:  # the tests that need the checker will say so themselves
+        print(f"abort trace not installed: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -30,5 +30,11 @@ def test_bench_line_fields(golden_dir):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    # the fraction is a bound (compulsory bytes / time / peak); the no-reuse traffic model sits beside it
+    assert 0 < r["frac"] <= 1.0 and r["frac_model_no_reuse"] >= r["frac"]
+    assert all(0 < f <= 1.0 for f in r["bounds"]["frac_of_each"].values())
+    assert r["bounds"]["frac_of_tightest"] == max(r["bounds"]["frac_of_each"].values())
+    # counters of a committed profile are used only beside the sources they were measured on
+    assert (r["traffic"] is None) == (r["traffic_stale"] is not None)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "GFLOP/s" and c["sample"]

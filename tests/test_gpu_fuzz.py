@@ -50,8 +50,8 @@ def random_matrix(rng, rows, cols):
     return hostcsr.HostCsr.from_coo(rows, cols, M.row_ids()[keep], M.col_idx[keep].astype(np.int64), M.val[keep]).sorted_rows()
 
 
-@pytest.mark.parametrize("seed", range(96))
-def test_random_structure_and_options(seed):
+def make_case(seed):
+    """(A, B, engine options) of fuzz case `seed`."""
     rng = np.random.default_rng(1000 + seed)
     m, k, n = (int(x) for x in rng.integers(40, 2500, 3))
     if seed % 3 == 0:
@@ -83,6 +83,15 @@ def test_random_structure_and_options(seed):
         rp = B.row_ptr.astype(np.int64)
         order = np.concatenate([np.arange(rp[i + 1] - 1, rp[i] - 1, -1) for i in range(B.rows)]) if B.nnz else np.zeros(0, np.int64)
         B = hostcsr.HostCsr(B.rows, B.cols, B.row_ptr, B.col_idx[order], B.val[order])
+    return A, B, opts
+
+
+N_CASES = 96
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_random_structure_and_options(seed):
+    A, B, opts = make_case(seed)
     ctx = capi.Context(0)
     try:
         for name, value in opts.items():
@@ -95,5 +104,7 @@ def test_random_structure_and_options(seed):
             dC.free()
             E = orc.spgemm(to_o(A), to_o(B))
             orc.assert_same(orc.OCsr(A.rows, B.cols, rp, ci, v), E, rtol=0.0)
+        dA.free()
+        dB.free()
     finally:
-        ctx.close()
+        ctx.close()  # (frees whatever a failed case left alive on the context)

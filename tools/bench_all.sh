@@ -1,6 +1,6 @@
 # the four single-GPU workloads, one JSON line each into gpurun_out/bench_<w>.json
 for w in shell diel er rmat; do
-  timeout -k 10 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || { tail -3 gpurun_out/bench_$w.err; exit 1; }
+  timeout -k 10 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-also > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err || { tail -3 gpurun_out/bench_$w.err; exit 1; }
   python - <<PY
 import json
 d=json.load(open('gpurun_out/bench_$w.json'))

@@ -11,6 +11,9 @@ HBM bytes per launch of a kernel (largest dispatch of that kernel in the run):
 """
 import collections, csv, glob, json, os, shutil, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # csrc_digest: names the sources the profiled library was built from
+
 src, tag = sys.argv[1], sys.argv[2]
 
 
@@ -52,8 +55,8 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
             "TCC_HIT": wq.get(k, {}).get("TCC_HIT_sum"), "TCC_MISS": wq.get(k, {}).get("TCC_MISS_sum"), "grid": rd[k]["_grid"]}
         if k in sq:  # wave-instructions issued and LDS-array cycles of the same launch
             out[k.replace("sg::", "")]["sq"] = {c: v for c, v in sq[k].items() if c != "_grid"}
-    json.dump({"workload": w,
-               "command": f"rocprofv3 --pmc <one counter group per run> -- python3 bench.py --workload {w} --steps 1 --warmup 0 --no-cpu-baseline",
+    json.dump({"workload": w, "csrc_sha1": bench.csrc_digest(),
+               "command": f"rocprofv3 --pmc <one counter group per run> -- python3 bench.py --workload {w} --steps 1 --warmup 0 --no-cpu-baseline --no-also",
                "kernels": out}, open(f"profiles/{tag}_traffic_{w}.json", "w"), indent=1)
     stats = glob.glob(f"{wdir}/trace/**/*kernel_stats.csv", recursive=True)
     if stats:
