@@ -111,6 +111,12 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   walk_tail                                       window kernels fetch entries 64..127 of a row of B
  *                                                   ahead with its first 64: 0 no, 1 yes, 2 (default)
  *                                                   where B's rows hold 48 entries and more on average
+ *   grp_runs                                        1 (default): where consecutive entries of an A row select
+ *                                                   consecutive rows of B that have ONE column list (the
+ *                                                   unknowns of a mesh node), the window kernels walk the list
+ *                                                   once per run: the symbolic one skips the repeats, the
+ *                                                   row-group numeric one ranks a column once and sums the
+ *                                                   run's products in registers, in the CPU's order; 0: row by row
  *   short_packed                                    1: the numeric one reads the rows of B as 16-byte
  *                                                   {column, value} records padded to 128-byte lines
  *                                                   (built once per B handle, at most 7 records of

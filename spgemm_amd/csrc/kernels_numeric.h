@@ -267,6 +267,248 @@ __global__ void __launch_bounds__(256)
   if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
 }
 
+// The same accumulation with the A row walked run by run (RowRuns / RunPipe): where consecutive A
+// entries select consecutive rows of B with ONE column list (the unknowns of a mesh node: 5 rows in
+// a row for af_shell10, 3 for dielFilterV3real), the output position of a column is found once per
+// run instead of once per B row, and every accumulator it feeds is read from LDS once, takes the
+// run's products one after the other in registers - the order of the CPU loop - and is written
+// back once: two plain LDS accesses per row of the group and run instead of one LDS floating-point
+// add (a read-modify-write that keeps the LDS busy five times as long) per row and B entry.  A run
+// of one B row takes the single LDS add as before.  The row's description sits in registers, so
+// the B entries of two units are in flight while a third is consumed.
+// WIDE: A rows of up to 128 entries, else 64.  GMAX: rows a group of the launch has at most; the LDS
+// holds GMAX accumulator rows per wavefront, and the inner loops run over all GMAX of them without
+// a test per row (a group of fewer rows multiplies zeros into rows that are never written out).
+#ifndef SG_GRP_SLOTS
+#define SG_GRP_SLOTS 2
+#endif
+#ifndef SG_GRP_ALDS
+#define SG_GRP_ALDS 0
+#endif
+constexpr int GRP_RUN_SLOTS = SG_GRP_SLOTS;
+// SG_GRP_ALDS: the A values of the group's rows are staged in LDS and read back as broadcasts (one LDS
+// read per row of the group and B row) instead of being handed from a lane to the scalar unit (two
+// lane reads): fewer vector instructions, more LDS traffic and 8 * GMAX * 64 (128) bytes of LDS more.
+constexpr bool GRP_RUN_ALDS = SG_GRP_ALDS != 0;
+__host__ __device__ inline size_t grp_run_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, bool wide) {
+  return grp_region(compact, words, cap, gmax, 0) + (GRP_RUN_ALDS ? (size_t)gmax * (wide ? 128u : 64u) * 8u : 0u);
+}
+// TCN: registers of 64 columns that hold a group's column list (cap <= 64 * TCN)
+template <bool WIDE, bool COMPACT, int RMAX, int GMAX, int TCN_>
+__global__ void __launch_bounds__(256)
+    k_num_grp_run(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, const uint32_t *__restrict__ same_bits,
+                  RowMeta m, NumOut o, uint32_t words, uint32_t cap, uint32_t wpb, uint32_t rpw) {
+  // A wavefront takes rpw (<= 64) consecutive groups of its bin, one after the other.  What a group
+  // needs before its first product sits behind a chain of dependent loads (row id -> row state ->
+  // column indices of the A row -> bounds of the B rows -> B entries); that chain is taken off the
+  // critical path: the row state of ALL the wavefront's groups is loaded once (lane i holds group i's),
+  // the description of the next group's A row is loaded while this group is accumulated (the column
+  // indices of the group after it as well), and so is the next group's column list.
+  constexpr uint32_t gmax = GMAX;
+#ifdef SG_GRP_STAMPS
+  // diagnostic build: cycles per phase, summed over the wavefronts into o.zero_count[8..]
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define GR_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define GR_STAMP(i)
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
+  if (w >= wpb || first64 >= nrows) return;
+  const uint32_t first = (uint32_t)first64, ng = min(rpw, nrows - first);
+  const size_t region = grp_run_region(COMPACT, words, cap, gmax, WIDE);
+  constexpr uint32_t ALEN = WIDE ? 128u : 64u;
+  const uint32_t topw = COMPACT ? grp_top_words(words) : 0u;
+  uint64_t *top = reinterpret_cast<uint64_t *>(smem + w * region);
+  uint32_t *top32 = reinterpret_cast<uint32_t *>(top);
+  uint64_t *cw = top + topw;
+  uint32_t *cw32 = reinterpret_cast<uint32_t *>(cw);
+  double *vals = reinterpret_cast<double *>(cw + (COMPACT ? cap : words));
+  double *avals = vals + (size_t)gmax * cap; // (SG_GRP_ALDS) A values: avals[j * ALEN + t]
+  constexpr uint32_t gmaxc = GMAX;
+  static_assert(GMAX <= (int)(WIDE ? GRP_MAX_WIDE : GRP_MAX), "more rows than a group can have");
+  // row state of the wavefront's groups: lane i holds group i's (the lanes past the last group repeat it)
+  const uint32_t st_row = rows[first + min(lane, ng - 1u)];
+  const uint32_t st_cnt = min((uint32_t)m.gcnt[st_row], gmax);
+  const uint32_t st_cmin = m.cmin[st_row], st_cmax = m.cmax[st_row], st_n = m.nnz[st_row];
+  const uint64_t st_toff = m.t_off[st_row], st_a0 = A.ptr[st_row], st_coff = o.c_ptr[st_row];
+  const uint32_t st_len = (uint32_t)min(A.ptr[(uint64_t)st_row + 1u] - st_a0, (uint64_t)ALEN);
+  auto rl32 = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+  constexpr uint32_t TCN = TCN_;
+  // the group's column list; a lane past its end re-reads the last entry (n >= 1 for every row of this bin)
+  auto load_tc = [&](uint32_t g, uint32_t (&tc)[TCN]) {
+    const uint32_t *tin = m.temp_cols + readlane64(st_toff, g);
+    const uint32_t n = rl32(st_n, g);
+#pragma unroll
+    for (uint32_t u = 0; u < TCN; ++u) tc[u] = tin[min(64u * u + lane, n - 1u)];
+  };
+  RowRuns<WIDE> cur, nxt;
+  cur.issue_a(A, readlane64(st_a0, 0), max(rl32(st_len, 0), 1u), lane);
+  {
+    const uint32_t g1 = min(1u, ng - 1u);
+    nxt.issue_a(A, readlane64(st_a0, g1), max(rl32(st_len, g1), 1u), lane);
+  }
+  cur.issue_b(B, same_bits);
+  uint32_t tc[TCN];
+  load_tc(0u, tc);
+  uint32_t nz = 0;
+  GR_STAMP(0) // row state of all groups, first descriptions issued
+  for (uint32_t g = 0; g < ng; ++g) {
+    const uint32_t g1 = min(g + 1u, ng - 1u), g2 = min(g + 2u, ng - 1u);
+    // this group's scalars
+    const uint32_t cnt = rl32(st_cnt, g);
+    const uint32_t base = rl32(st_cmin, g) & ~31u;
+    const uint32_t nw = ((rl32(st_cmax, g) - base) >> 5) + 1u;
+    const uint32_t n = rl32(st_n, g);
+    const uint64_t a0 = readlane64(st_a0, g), coff = readlane64(st_coff, g);
+    const uint32_t len_a = rl32(st_len, g);
+    cur.len_a = len_a; // (a row without entries cannot be here; the loads above assumed one entry at least)
+    cur.finish(lane);
+    // the next group's description: bounds of its B rows now, column indices of the group after it
+    nxt.issue_b(B, same_bits);
+    RowRuns<WIDE> aft;
+    aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);
+    GR_STAMP(1) // waited for this group's description
+    const uint32_t ntop = (nw + 31u) >> 5;
+    if constexpr (COMPACT) {
+      for (uint32_t i = lane; i < ntop; i += 64) top[i] = 0ull;
+      for (uint32_t i = lane; i < n; i += 64) cw[i] = 0ull;
+    } else {
+      for (uint32_t i = lane; i < nw; i += 64) cw[i] = 0ull;
+    }
+    // A values of row j: entries lane and 64 + lane (the rows of a group lie back to back in A and in C)
+    double av_lo[gmaxc], av_hi[gmaxc];
+#pragma unroll
+    for (uint32_t j = 0; j < gmaxc; ++j) {
+      av_lo[j] = 0.0;
+      av_hi[j] = 0.0;
+      if (j < cnt) {
+        for (uint32_t i = lane; i < n; i += 64) vals[j * cap + i] = 0.0;
+        const double *av = A.val + a0 + (uint64_t)j * len_a;
+        if (lane < len_a) av_lo[j] = av[lane];
+        if constexpr (WIDE)
+          if (64u + lane < len_a) av_hi[j] = av[64u + lane];
+      }
+      if constexpr (GRP_RUN_ALDS) { // (rows past the group's end hold zeros)
+        avals[j * ALEN + lane] = av_lo[j];
+        if constexpr (WIDE) avals[j * ALEN + 64u + lane] = av_hi[j];
+      }
+    }
+    // the first units' B entries: in flight during the rest of the set-up
+    RunPipe<RMAX, true, GRP_RUN_SLOTS, WIDE> pipe;
+    pipe.begin(B, cur, lane);
+    lds_fence();
+#pragma unroll
+    for (uint32_t u = 0; u < TCN; ++u) {
+      const uint32_t p = 64u * u + lane;
+      if (64u * u < n && p < n) {
+        const uint32_t c = tc[u];
+#pragma unroll
+        for (uint32_t j = 0; j < gmaxc; ++j)
+          if (j < cnt) o.c_col[coff + (uint64_t)j * n + p] = c;
+        const uint32_t cc = c - base, wi = cc >> 5;
+        if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
+        else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
+      }
+    }
+    lds_fence();
+    uint32_t ncw = nw;
+    auto compact_word = [&](uint32_t wi) {
+      if constexpr (!COMPACT) return wi;
+      const uint64_t t = top[wi >> 5];
+      return (uint32_t)(t >> 32) + __popc((uint32_t)t & ((1u << (wi & 31u)) - 1u));
+    };
+    if constexpr (COMPACT) {
+      ncw = 0;
+      for (uint32_t r0 = 0; r0 < ntop; r0 += 64) {
+        const uint32_t ti = r0 + lane;
+        const uint32_t pc = ti < ntop ? __popc(top32[ti * 2u]) : 0u;
+        const uint32_t incl = group_incl_scan<64>(pc);
+        if (ti < ntop) top32[ti * 2u + 1u] = ncw + incl - pc;
+        ncw += group_last<64>(incl);
+      }
+      lds_fence();
+#pragma unroll
+      for (uint32_t u = 0; u < TCN; ++u)
+        if (64u * u < n && 64u * u + lane < n) {
+          const uint32_t cc = tc[u] - base;
+          atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
+        }
+      lds_fence();
+    }
+    uint32_t carry = 0;
+    for (uint32_t r0 = 0; r0 < ncw; r0 += 64) {
+      const uint32_t ci = r0 + lane;
+      const uint32_t pc = ci < ncw ? __popc(cw32[ci * 2u]) : 0u;
+      const uint32_t incl = group_incl_scan<64>(pc);
+      if (ci < ncw) cw32[ci * 2u + 1u] = carry + incl - pc;
+      carry += group_last<64>(incl);
+    }
+    lds_fence();
+    // the next group's column list (this group's is used up)
+    load_tc(g1, tc);
+    GR_STAMP(2) // bitmap and prefix counts built, columns of C stored
+    // value of A entry t of the group's row j (t wave-uniform)
+    auto a_of = [&](uint32_t j, uint32_t t) {
+      if constexpr (GRP_RUN_ALDS) return avals[j * ALEN + t];
+      else if constexpr (WIDE) return t < 64u ? readlane_f64(av_lo[j], t) : readlane_f64(av_hi[j], t - 64u);
+      else return readlane_f64(av_lo[j], t);
+    };
+    pipe.run(B, cur, lane, [&](const RunInfo &ri, const RunVec<RMAX> &v) {
+      lds_fence(); // the unit before has left its sums in LDS
+      if (v.ok) {
+        const uint32_t cc = v.col - base;
+        const uint64_t e = cw[compact_word(cc >> 5)];
+        const uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
+        double *acc_at = vals + pos;
+        if (ri.rl == 1u) { // wave-uniform
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) lds_add_f64(acc_at + j * cap, __dmul_rn(a_of(j, ri.t0), v.bv[0]));
+        } else {
+          double acc[gmaxc];
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = acc_at[j * cap];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if ((uint32_t)r < ri.rl) { // wave-uniform
+#pragma unroll
+              for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a_of(j, ri.t0 + (uint32_t)r), v.bv[r]));
+            }
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) acc_at[j * cap] = acc[j];
+        }
+      }
+    });
+    lds_fence();
+    GR_STAMP(3) // the units
+#pragma unroll
+    for (uint32_t j = 0; j < gmaxc; ++j) {
+      if (j < cnt) {
+        const uint64_t off = coff + (uint64_t)j * n;
+        for (uint32_t p = lane; p < n; p += 64) {
+          double v = vals[j * cap + p];
+          o.c_val[off + p] = v;
+          nz += (v == 0.0) ? 1u : 0u;
+        }
+      }
+    }
+    lds_fence();
+    cur = nxt;
+    nxt = aft;
+    GR_STAMP(4) // values written
+  }
+  nz = group_sum<64>(nz);
+  if (lane == 0 && nz) atomicAdd(o.zero_count, (unsigned long long)nz);
+#ifdef SG_GRP_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&o.zero_count[8 + i], tph[i]);
+#endif
+#undef GR_STAMP
+}
+
 // numeric, hash path: one wavefront per row.
 // LDS per wavefront: vals[S/2] double | keys[S] uint32 | pos[S] uint16 (= 10*S bytes; nnz <= S/2)
 //                    | FLAT only: owner[S/2] uint32 + flat-walk scratch.

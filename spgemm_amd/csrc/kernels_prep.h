@@ -17,37 +17,64 @@ struct RowInfo {
   uint4 *p;
   uint32_t sh;
   uint64_t hi_base;
+  // one bit per row: the row has the column list of the row before it (same length, same columns in
+  // the same, strictly increasing, order).  Consecutive entries of an A row that select such rows walk
+  // one column list several times: the window kernels rank it once (kernels_numeric.h, RunWalk).
+  uint32_t *same;
   __device__ __forceinline__ uint4 &lo(uint64_t k) const { return p[k << sh]; }
   __device__ __forceinline__ uint4 &hi(uint64_t k) const { return p[hi_base + (k << sh)]; }
 };
 
+// `same` is zero on entry; p[2 * rows].y receives the longest run of rows with one column list (capped at 255).
 __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t *__restrict__ b_ptr,
                                                    const uint32_t *__restrict__ b_col,
                                                    RowInfo info) {
   constexpr int G = 8;
   uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   uint32_t lg = threadIdx.x & (G - 1);
-  uint32_t mn = 0xFFFFFFFFu, mx = 0, unsorted = 0;
-  uint64_t b0 = 0, b1 = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0, unsorted = 0, differs = 0;
+  uint64_t b0 = 0, b1 = 0, bp = 0;
   if (row < rows) {
     b0 = b_ptr[row];
     b1 = b_ptr[row + 1];
+    bp = row ? b_ptr[row - 1] : b0;
   }
+  const uint64_t len = b1 - b0;
+  const bool cmp = row > 0 && len > 0 && b0 - bp == len; // the row before is as long: compare the columns
   for (uint64_t j = b0 + lg; j < b1; j += G) {
     uint32_t c = b_col[j];
     if (j > b0 && b_col[j - 1] >= c) unsorted = 1;
+    if (cmp && b_col[j - len] != c) differs = 1;
     mn = min(mn, c);
     mx = max(mx, c);
   }
   mn = group_min<G>(mn);
   mx = group_max<G>(mx);
   unsorted = group_max<G>(unsorted);
+  differs = group_max<G>(differs);
   if (row < rows && lg == 0) {
-    uint64_t len = b1 - b0;
     info.lo(row) = make_uint4(mn, mx, len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len, unsorted);
     info.hi(row) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), 0u, 0u);
     if (unsorted) atomicAdd(&info.p[2 * rows].x, 1u);
+    if (cmp && !differs && !unsorted && len <= 0xFFFFFFFFull) atomicOr(&info.same[row >> 5], 1u << (row & 31u));
   }
+}
+
+// longest run of rows with one column list: a row that starts one (its own bit clear, the next row's
+// set) counts the set bits that follow it, up to `cap` rows in all
+__global__ void __launch_bounds__(256) k_b_maxrun(uint64_t rows, RowInfo info, uint32_t cap) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t run = 0;
+  if (r + 1 < rows) {
+    auto bit = [&](uint64_t k) { return (info.same[k >> 5] >> (k & 31u)) & 1u; };
+    if (!bit(r) && bit(r + 1)) {
+      run = 2;
+      while (run < cap && r + run < rows && bit(r + run)) ++run;
+    }
+  }
+  run = group_max<64>(run);
+  if ((threadIdx.x & 63u) == 0 && run > 1 && run > __hip_atomic_load(&info.p[2 * rows].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&info.p[2 * rows].y, run);
 }
 
 // ---- B rows as padded 16-byte records, for the short-row numeric kernel ------------------------------

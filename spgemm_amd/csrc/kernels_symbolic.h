@@ -15,14 +15,17 @@ namespace sg {
 // saved).  The sorted column list is then written coalesced: output position p finds the word
 // that holds the p-th set bit by a binary search over the per-word prefix counts.
 // FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
+// same_bits (scalar walk; may be null): RowInfo::same of B - consecutive A entries that select consecutive rows
+// of B with one column list are walked once.
 // LDS per wavefront: bits u32[words] | prefix u16[words] (rounded up to 16 bytes) | flat-walk scratch
 __host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
   return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
 }
+constexpr int SYM_RUN_SLOTS = 6;
 template <bool FLAT, bool TAIL = false> // TAIL: see RowWalk (scalar walk only)
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
-                 uint32_t words) {
+                 uint32_t words, const uint32_t *__restrict__ same_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform on the scalar unit
@@ -41,8 +44,23 @@ __global__ void __launch_bounds__(256)
     uint32_t c = col - base;
     atomicOr(&bm[c >> 5], 1u << (c & 31u));
   };
-  if constexpr (FLAT) flat_walk<false>(A, B, row, lane, smem + w * region + sym_window_region(words, false), mark);
-  else wave_row_walk<false, false, TAIL>(A, B, row, lane, mark);
+  if constexpr (FLAT) {
+    flat_walk<false>(A, B, row, lane, smem + w * region + sym_window_region(words, false), mark);
+  } else {
+    const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
+    if (same_bits && a1 - a0 <= 128u) { // wave-uniform
+      // B has runs of rows with one column list and the A row is short: its description goes to
+      // registers (RowRuns), only the first row of every run is walked, and the columns of
+      // SYM_RUN_SLOTS - 1 of them are in flight while one is ORed in
+      RowRuns<true> runs;
+      runs.load(A, B, same_bits, a0, (uint32_t)(a1 - a0), lane);
+      RunPipe<255, false, SYM_RUN_SLOTS, true> pipe;
+      pipe.begin(B, runs, lane);
+      pipe.run(B, runs, lane, [&](const RunInfo &, const RunVec<1> &v) { mark(v.ok ? v.col : EMPTY_KEY, 0.0, 0.0, 0u); });
+    } else {
+      wave_row_walk<false, false, TAIL>(A, B, row, lane, mark, same_bits); // (an entry that repeats a column list is skipped)
+    }
+  }
   lds_fence();
   // per-word prefix of the set-bit counts (16 bits: the hull of the window path is at most 65,536
   // columns wide, so fewer than 65,536 bits lie before any word)

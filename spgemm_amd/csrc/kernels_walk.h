@@ -69,9 +69,13 @@ template <bool WITH_AVAL> struct WalkInfo {
   double av[PF];     // value of the A entry
 };
 
+// same_bits (may be null): one bit per row of B, set when the row has the column list of the row
+// before it.  A pattern-only walk then skips an A entry that selects the row after the one its
+// predecessor selected when that bit is set: the entry adds no new column (a0: first entry of the row).
 template <bool WITH_AVAL>
 __device__ __forceinline__ void walk_scalar_stage(const Csr &A, const Csr &B, uint64_t ka, uint64_t a1,
-                                                  WalkInfo<WITH_AVAL> &s) {
+                                                  WalkInfo<WITH_AVAL> &s, const uint32_t *same_bits = nullptr,
+                                                  uint64_t a0 = 0) {
   const auto a_col = scalar_view(A.col);
   const auto a_val = scalar_view(A.val);
   const auto b_ptr = scalar_view(B.ptr);
@@ -103,6 +107,16 @@ __device__ __forceinline__ void walk_scalar_stage(const Csr &A, const Csr &B, ui
   }
 #pragma unroll
   for (int u = 0; u < PF; ++u) s.len[u] = (ka + u < a1) ? (uint32_t)(p1[u] - s.p0[u]) : 0u;
+  if (same_bits) { // wave-uniform
+    const auto sb = scalar_view(same_bits);
+    uint32_t kprev = ka > a0 ? a_col[ka - 1] : 0xFFFFFFFEu; // (no entry before the first: never k - 1)
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t w = sb[k[u] >> 5];
+      if (k[u] == kprev + 1u && ((w >> (k[u] & 31u)) & 1u)) s.len[u] = 0u;
+      kprev = k[u];
+    }
+  }
 }
 
 // TAIL: entries 64..127 of every B row are fetched here as well (c2, v2) instead of by the consumer.
@@ -132,14 +146,15 @@ template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false> struct Ro
   WalkInfo<WITH_AVAL> s_cur, s_next;
   uint32_t c_cur[PF], c2_cur[PF];
   double v_cur[PF], v2_cur[PF];
+  const uint32_t *same_bits = nullptr; // pattern-only walks: skip entries that repeat a column list (see walk_scalar_stage)
 
   __device__ __forceinline__ void begin(const Csr &A, const Csr &B, uint32_t row, uint32_t lane) {
     const auto a_ptr = scalar_view(A.ptr);
     a0 = a_ptr[row];
     a1 = a_ptr[row + 1];
-    walk_scalar_stage<WITH_AVAL>(A, B, a0, a1, s_cur);
+    walk_scalar_stage<WITH_AVAL>(A, B, a0, a1, s_cur, same_bits, a0);
     walk_vector_stage<WITH_VAL, WITH_AVAL, TAIL>(B, s_cur, lane, c_cur, v_cur, c2_cur, v2_cur);
-    walk_scalar_stage<WITH_AVAL>(A, B, a0 + PF, a1, s_next);
+    walk_scalar_stage<WITH_AVAL>(A, B, a0 + PF, a1, s_next, same_bits, a0);
   }
 
   template <class F> __device__ __forceinline__ void run(const Csr &A, const Csr &B, uint32_t lane, F f) {
@@ -148,7 +163,7 @@ template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false> struct Ro
     double v_next[PF], v2_next[PF];
     for (uint64_t ka = a0; ka < a1; ka += PF) {
       walk_vector_stage<WITH_VAL, WITH_AVAL, TAIL>(B, s_next, lane, c_next, v_next, c2_next, v2_next);
-      walk_scalar_stage<WITH_AVAL>(A, B, ka + 2 * PF, a1, s_after);
+      walk_scalar_stage<WITH_AVAL>(A, B, ka + 2 * PF, a1, s_after, same_bits, a0);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const uint32_t apos = (uint32_t)(ka - a0) + u;
@@ -181,11 +196,204 @@ template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false> struct Ro
 };
 
 template <bool WITH_VAL, bool WITH_AVAL = WITH_VAL, bool TAIL = false, class F>
-__device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f) {
+__device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32_t row, uint32_t lane, F f,
+                                              const uint32_t *same_bits = nullptr) {
   RowWalk<WITH_VAL, WITH_AVAL, TAIL> w;
+  w.same_bits = same_bits;
   w.begin(A, B, row, lane);
   w.run(A, B, lane, f);
 }
+
+// ---- walking an A row run by run -----------------------------------------------------------------
+// For A rows of up to 128 entries (the row groups of the window path).  A run = up to RMAX
+// consecutive entries of the A row that select CONSECUTIVE rows k, k + 1, ... of B which all have
+// one column list (RowInfo::same).  Such rows lie back to back in B's arrays, so entry j of row
+// k + r sits at p0 + r * L + j (p0: start of row k, L: the common length).  A unit of the walk is one
+// chunk of 64 columns of one run: lane j holds column p0[chunk * 64 + j] once and the value of that
+// column in each of the run's rows.  The consumer finds the column's output position once per unit
+// and adds the run's products to it row after row - the order of the CPU loop, since the entries of
+// a run are consecutive in the A row and the lanes of a unit hold distinct columns.
+//
+// The description of the whole A row lives in registers: lane t holds, for the entries t and 64 + t,
+// the start and the length of the B row and whether the entry continues a run; it is loaded once,
+// when the kernel starts, and the units are then enumerated with lane reads only.  No load of the
+// walk depends on another load after that, so the B entries of DEPTH units are in flight while
+// one is consumed (the kernels that walk a row through dependent scalar loads have one stage in
+// flight and are bound by the latency of that chain).
+struct RunInfo { // wave-uniform
+  uint64_t p0;  // start of the first B row of the run
+  uint32_t L;   // entries of each of its B rows
+  uint32_t rl;  // B rows (= A entries) in the run, 1..RMAX
+  uint32_t t0;  // position of its first entry in the A row
+  uint32_t chunk;
+  bool valid;
+};
+template <int NV> struct RunVec {
+  uint32_t col;     // the lane's column of this unit
+  bool ok;          // ... if it holds one
+  double bv[NV];    // the column's value in the run's rows (rows past the run's end repeat the last one); pattern walks: unused
+};
+template <bool WIDE> struct RowRuns {
+  // per lane: entry t (lo) and 64 + t (hi, WIDE only)
+  uint64_t p0_lo, p0_hi;
+  uint32_t len_lo, len_hi;
+  uint64_t start_lo, start_hi; // wave-uniform: entries that begin a run
+  uint32_t len_a;
+  // iterator (wave-uniform)
+  uint32_t t, run_end, rl, L, chunk;
+  uint64_t p0;
+  bool done;
+
+  // The description is loaded in two dependent steps, which a kernel that walks several rows one
+  // after the other issues a row (and two rows) ahead: issue_a() loads the row's column indices k,
+  // issue_b() the bounds of the B rows k and their `same` bits, finish() (once those have landed)
+  // finds the runs.  Every lane issues every load (a lane past the row's end re-reads the row's
+  // last entry): the count of loads in flight does not depend on the row.  len >= 1.
+  uint32_t k_lo, k_hi;
+  uint32_t bits_lo, bits_hi; // the words of same_bits that hold the lane's rows
+  uint64_t p1_lo, p1_hi;     // ends of the lane's B rows
+  __device__ __forceinline__ void issue_a(const Csr &A, uint64_t a0, uint32_t len, uint32_t lane) {
+    len_a = len;
+    k_lo = A.col[a0 + min(lane, len - 1u)];
+    k_hi = 0;
+    if constexpr (WIDE) k_hi = A.col[a0 + min(64u + lane, len - 1u)];
+  }
+  __device__ __forceinline__ void issue_b(const Csr &B, const uint32_t *__restrict__ same_bits) {
+    p0_lo = B.ptr[k_lo];
+    p1_lo = B.ptr[(uint64_t)k_lo + 1u];
+    bits_lo = same_bits[k_lo >> 5];
+    p0_hi = p1_hi = 0; bits_hi = 0;
+    if constexpr (WIDE) {
+      p0_hi = B.ptr[k_hi];
+      p1_hi = B.ptr[(uint64_t)k_hi + 1u];
+      bits_hi = same_bits[k_hi >> 5];
+    }
+  }
+  __device__ __forceinline__ void finish(uint32_t lane) {
+    const uint32_t len = len_a;
+    len_lo = lane < len ? (uint32_t)min(p1_lo - p0_lo, (uint64_t)0xFFFFFFFFu) : 0u;
+    // an entry continues a run when it selects the row after the one its predecessor selects and
+    // that row repeats the predecessor's column list
+    uint32_t kp_lo = __shfl_up(k_lo, 1, 64);
+    if (lane == 0) kp_lo = k_lo; // (the first entry never continues one)
+    const bool cont_lo = lane < len && ((bits_lo >> (k_lo & 31u)) & 1u) && k_lo == kp_lo + 1u;
+    start_lo = __ballot(lane < len && !cont_lo);
+    start_hi = 0;
+    len_hi = 0;
+    if constexpr (WIDE) {
+      len_hi = 64u + lane < len ? (uint32_t)min(p1_hi - p0_hi, (uint64_t)0xFFFFFFFFu) : 0u;
+      uint32_t kp_hi = __shfl_up(k_hi, 1, 64);
+      const uint32_t k63 = (uint32_t)__builtin_amdgcn_readlane((int)k_lo, 63);
+      if (lane == 0) kp_hi = k63;
+      const bool cont_hi = 64u + lane < len && ((bits_hi >> (k_hi & 31u)) & 1u) && k_hi == kp_hi + 1u;
+      start_hi = __ballot(64u + lane < len && !cont_hi);
+    }
+    t = 0; run_end = 0; rl = 0; L = 0; chunk = 0; p0 = 0;
+    done = len == 0;
+  }
+  // the whole description at once, for A row [a0, a0 + len); len <= 64 (128 when WIDE); len == 0: no unit
+  __device__ __forceinline__ void load(const Csr &A, const Csr &B, const uint32_t *__restrict__ same_bits, uint64_t a0,
+                                       uint32_t len, uint32_t lane) {
+    if (len == 0) { // wave-uniform
+      len_a = 0; done = true; rl = 0; L = 0; chunk = 0; t = 0; run_end = 0; p0 = 0; start_lo = start_hi = 0;
+      p0_lo = p0_hi = 0; len_lo = len_hi = 0;
+      return;
+    }
+    issue_a(A, a0, len, lane);
+    issue_b(B, same_bits);
+    finish(lane);
+  }
+  // first entry >= from that begins a run (len_a when there is none)
+  __device__ __forceinline__ uint32_t next_start(uint32_t from) const {
+    if (from < 64u) {
+      const uint64_t m = start_lo >> from;
+      if (m) return from + (uint32_t)__builtin_ctzll(m);
+      from = 64u;
+    }
+    if constexpr (WIDE) {
+      if (from < 128u) {
+        const uint64_t m = start_hi >> (from - 64u);
+        if (m) return from + (uint32_t)__builtin_ctzll(m);
+      }
+    }
+    return len_a;
+  }
+  // the next unit, RMAX rows of a run at most
+  template <int RMAX> __device__ __forceinline__ RunInfo next() {
+    RunInfo r{0, 0, 1, 0, 0, false};
+    if (done) return r;
+    if (rl != 0 && (chunk + 1u) * 64u < L) { // more columns of the same rows
+      ++chunk;
+    } else {
+      t += rl; // (0 before the first unit)
+      if (t >= len_a) { done = true; return r; }
+      if (t >= run_end) run_end = next_start(t + 1u);
+      rl = min(run_end - t, (uint32_t)RMAX);
+      chunk = 0;
+      if constexpr (WIDE) {
+        if (t < 64u) { p0 = readlane64(p0_lo, t); L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t); }
+        else { p0 = readlane64(p0_hi, t - 64u); L = (uint32_t)__builtin_amdgcn_readlane((int)len_hi, (int)(t - 64u)); }
+      } else {
+        p0 = readlane64(p0_lo, t);
+        L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t);
+      }
+    }
+    r.p0 = p0; r.L = L; r.rl = rl; r.t0 = t; r.chunk = chunk; r.valid = true;
+    return r;
+  }
+};
+// Issues the loads of a unit.  Every lane issues every load (a lane past the end of the B rows,
+// a row past the end of the run and an exhausted walk read an address that is always valid: the
+// run's first entry, or entry 0 of B): the number of loads in flight is then the same on every path
+// through the loop, which lets the compiler wait for exactly the unit it is about to consume.
+template <int RMAX, bool WITH_VAL>
+__device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32_t lane, RunVec<WITH_VAL ? RMAX : 1> &v) {
+  const uint32_t j = s.chunk * 64u + lane;
+  v.ok = s.valid && j < s.L;
+  const uint64_t base = (s.valid && s.L) ? s.p0 : 0ull;
+  // (the rows of B walked here are strictly increasing rows of a window row: at most 65,536 entries.
+  //  The mask tells the compiler that the byte offset fits 32 bits: scalar base + 32-bit lane offset.)
+  const uint32_t jj = (v.ok ? j : 0u) & 0xFFFFFu;
+  v.col = (B.col + base)[jj];
+  if constexpr (WITH_VAL) {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const uint32_t rr = min((uint32_t)r, s.rl - 1u);
+      // (wave-uniform: the row's base address is kept on the scalar unit, the lane adds a 32-bit offset)
+      const uint64_t rowp = (uint64_t)(uintptr_t)(B.val + base + (uint64_t)rr * s.L);
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rowp);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rowp >> 32));
+      typedef const double __attribute__((address_space(1))) *global_f64_ptr; // (global memory, not a generic address)
+      v.bv[r] = ((global_f64_ptr)(uintptr_t)(((uint64_t)hi << 32) | lo))[jj];
+    }
+  }
+}
+
+// The units of a row, SLOTS of them in flight: begin() issues the first SLOTS fetches (to be
+// overlapped with the kernel's set-up), run() consumes a unit and refills its slot.
+// f(info, vec) is called once per unit by all lanes.
+template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
+  RunInfo info[SLOTS];
+  RunVec<WITH_VAL ? RMAX : 1> vec[SLOTS];
+  __device__ __forceinline__ void begin(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane) {
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      info[s] = rr.template next<RMAX>();
+      run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+    }
+  }
+  template <class F> __device__ __forceinline__ void run(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane, F f) {
+    for (;;) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (!info[s].valid) return; // the units come in order: the first empty slot ends the walk
+        f(info[s], vec[s]);
+        info[s] = rr.template next<RMAX>();
+        run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+      }
+    }
+  }
+};
 
 // ---- flat walk ---------------------------------------------------------------------------------
 // For rows whose B rows are short, one A entry per step leaves most lanes idle.  The flat walk

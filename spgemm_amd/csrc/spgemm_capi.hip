@@ -120,6 +120,8 @@ struct spgemm_ctx {
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
+  uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
+  uint32_t grp_rpw = 8;          // most groups one wavefront of the run kernel takes one after the other (<= 64)
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   void *d_pinned = nullptr; // the same buffer as the device addresses it (k_report writes results into it)
@@ -164,6 +166,7 @@ struct spgemm_ctx {
     uint32_t max_len_big = 0;        // longest A row among the big rows
     uint32_t gmax_narrow = GRP_MAX, gmax_wide = GRP_MAX_WIDE; // largest row group among rows of up to GRP_ALEN entries / longer
     bool b_sorted = false; // every B row has strictly increasing columns
+    uint32_t b_maxrun = 0; // longest run of rows of B with one column list (0 or 1: none)
   } plan;
   size_t arena_used = 0;
 };
@@ -317,8 +320,12 @@ static int launch_partition(spgemm_ctx *ctx, const uint8_t *key, uint32_t n, uin
   return SPGEMM_OK;
 }
 
+// layout of d_rowinfo: 2 * rows + 1 records of 16 bytes (the last one holds counters), then the
+// `same` bits (one per row, in 32-bit words)
+static size_t rowinfo_same_words(const spgemm_mat *B) { return (size_t)((B->rows + 31) / 32) + 1; }
 static RowInfo rowinfo_of(const spgemm_mat *B) {
-  return RowInfo{B->d_rowinfo, B->rowinfo_sh, B->rowinfo_sh ? 1ull : B->rows};
+  return RowInfo{B->d_rowinfo, B->rowinfo_sh, B->rowinfo_sh ? 1ull : B->rows,
+                 reinterpret_cast<uint32_t *>(B->d_rowinfo + 2 * B->rows + 1)};
 }
 
 static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
@@ -326,12 +333,14 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   spgemm_mat *mb = const_cast<spgemm_mat *>(B);
   // short rows of A (which read both halves of a record) need short rows of B
   mb->rowinfo_sh = B->nnz <= 32 * B->rows ? 1u : 0u;
-  TRY(pool_alloc(ctx, (2 * B->rows + 1) * sizeof(uint4), (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
-  HIP_TRY(hipMemsetAsync(mb->d_rowinfo + 2 * B->rows, 0, sizeof(uint4), ctx->stream)); // count of unsorted rows
+  TRY(pool_alloc(ctx, (2 * B->rows + 1) * sizeof(uint4) + rowinfo_same_words(B) * 4, (void **)&mb->d_rowinfo, &mb->bytes_rowinfo));
+  // counters (unsorted rows, longest run of rows with one column list) and the `same` bits start at zero
+  HIP_TRY(hipMemsetAsync(mb->d_rowinfo + 2 * B->rows, 0, sizeof(uint4) + rowinfo_same_words(B) * 4, ctx->stream));
   if (B->rows) {
     uint32_t blocks = div_up_u64(B->rows * 8, 256);
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                        rowinfo_of(B));
+    hipLaunchKernelGGL(k_b_maxrun, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, rowinfo_of(B), 255u);
     HIP_TRY(hipGetLastError());
   }
   return SPGEMM_OK;
@@ -448,6 +457,13 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
   raise_lds_limit(k_num_short<4, true>); raise_lds_limit(k_num_short<SH_STEPS, true>);
   raise_lds_limit(k_probe_lane_order);
+#define SG_RAISE_RUN(W, C, G, T) raise_lds_limit(k_num_grp_run<W, C, 3, G, T>); raise_lds_limit(k_num_grp_run<W, C, 5, G, T>); raise_lds_limit(k_num_grp_run<W, C, 8, G, T>);
+  SG_RAISE_RUN(false, false, 3, 2) SG_RAISE_RUN(false, false, 5, 2) SG_RAISE_RUN(false, false, 8, 2)
+  SG_RAISE_RUN(false, true, 3, 2) SG_RAISE_RUN(false, true, 5, 2) SG_RAISE_RUN(false, true, 8, 2)
+  SG_RAISE_RUN(false, false, 3, 8) SG_RAISE_RUN(false, false, 5, 8) SG_RAISE_RUN(false, false, 8, 8)
+  SG_RAISE_RUN(false, true, 3, 8) SG_RAISE_RUN(false, true, 5, 8) SG_RAISE_RUN(false, true, 8, 8)
+  SG_RAISE_RUN(true, false, 3, 8) SG_RAISE_RUN(true, false, 4, 8) SG_RAISE_RUN(true, true, 3, 8) SG_RAISE_RUN(true, true, 4, 8)
+#undef SG_RAISE_RUN
 }
 
 // ---- library ------------------------------------------------------------------------------------
@@ -734,6 +750,12 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "walk_tail") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "walk_tail must be 0, 1 or 2");
     ctx->walk_tail = (uint32_t)value;
+  } else if (n == "grp_rpw") {
+    if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "grp_rpw must be 1..64");
+    ctx->grp_rpw = (uint32_t)value;
+  } else if (n == "grp_runs") {
+    if (value > 1) return fail(SPGEMM_ERR_INVALID, "grp_runs must be 0 or 1");
+    ctx->grp_runs = (uint32_t)value;
   } else if (n == "short_packed") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0, 1 or 2");
     ctx->short_packed = (uint32_t)value;
@@ -1046,8 +1068,8 @@ struct HostCounts {
   uint32_t long_count;
   uint32_t gmax_seen[2]; // largest row group: narrow rows, wide rows
   uint32_t b_unsorted;  // B rows whose columns are not strictly increasing
+  uint32_t b_maxrun;    // longest run of rows of B with one column list (next to b_unsorted in the row info's counters)
   uint32_t max_len_big; // longest A row among the numeric phase's big rows
-  uint32_t pad;
   uint64_t nprod_parts[NPROD_SLOTS];
 };
 static_assert(sizeof(HostCounts) <= PINNED_BYTES, "pinned staging buffer too small");
@@ -1168,12 +1190,15 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
     rep.add(ctx, hc->bin_off, bin_off, (SYM_NBINS + 1) * 8);
     rep.add(ctx, &hc->total_a, t_off + rows, 8);
     rep.add(ctx, hc->nprod_parts, total_nprod, NPROD_SLOTS * 8);
-    rep.add(ctx, &hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 4);
+    rep.add(ctx, &hc->b_unsorted, &B->d_rowinfo[2 * B->rows].x, 8); // .x unsorted rows, .y longest run
     rep.add(ctx, hc->gmax_seen, long_count + 1, 8);
     TRY(rep.launch(ctx));
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const bool b_sorted = hc->b_unsorted == 0;
+  const uint32_t b_maxrun = ctx->grp_runs ? hc->b_maxrun : 0u;
+  // (only a B whose rows are all strictly increasing: the run walks rely on it)
+  const uint32_t *same_bits = b_maxrun >= 2 && b_sorted ? rowinfo_of(B).same : nullptr;
   const uint32_t gmax_narrow = std::min<uint32_t>(std::max<uint32_t>(hc->gmax_seen[0], 1), GRP_MAX);
   const uint32_t gmax_wide = std::min<uint32_t>(std::max<uint32_t>(hc->gmax_seen[1], 1), GRP_MAX_WIDE);
   st.nprod = 0;
@@ -1208,7 +1233,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       if (flat) sym_kern = k_sym_window<true, false>;
       else if (walk_tail(ctx, B)) sym_kern = k_sym_window<false, true>;
       hipLaunchKernelGGL(sym_kern, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
-                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words);
+                         region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words, same_bits);
     } else if (key < SYM_GLOBAL0) {
       uint32_t tier = (key - SYM_HASH0) >> 2;
       uint32_t log2s = 7 + tier;
@@ -1307,6 +1332,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
   pl.blk_hist = blk_hist; pl.blk_off = blk_off; pl.partial = partial; pl.bin_off = bin_off;
   pl.zero_count = zero_count; pl.pblocks = pblocks;
   pl.b_sorted = b_sorted;
+  pl.b_maxrun = b_maxrun;
   pl.valid = true;
   return SPGEMM_OK;
 }
@@ -1393,11 +1419,34 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       uint32_t words = (64u << st_) + 2u, cap = q == 0 ? 128u : q == 2 ? GRP_CAP_MID : GRP_CAP_TOP;
       const uint32_t gmax = tier ? pl.gmax_wide : pl.gmax_narrow;
       const uint32_t alen = tier == 0 ? GRP_ALEN : tier == 1 ? GRP_ALEN_MID : GRP_ALEN_WIDE;
-      const bool compact = ctx->grp_compact == 2 ? grp_use_compact(words, cap, gmax, alen) : ctx->grp_compact != 0;
-      size_t region = grp_region(compact, words, cap, gmax, alen);
+      // B has runs of rows with one column list: the kernel that ranks a column once per run and sums
+      // in registers; instantiated for runs of up to 3, 5, 8 rows of B and groups of up to 3, 5, 8
+      // (wide: 3, 4) rows of A, whose accumulator rows it keeps in LDS
+      const bool use_runs = pl.b_maxrun >= 2 && pl.b_sorted;
+      const int rsel = pl.b_maxrun <= 3 ? 0 : pl.b_maxrun <= 5 ? 1 : 2;
+      const int gsel = tier ? (gmax <= 3 ? 0 : 1) : (gmax <= 3 ? 0 : gmax <= 5 ? 1 : 2);
+      const uint32_t gmax_lds = !use_runs ? gmax : tier ? (gsel ? 4u : 3u) : (gsel == 0 ? 3u : gsel == 1 ? 5u : 8u);
+      const bool compact = ctx->grp_compact == 2 ? grp_use_compact(words, cap, gmax_lds, alen) : ctx->grp_compact != 0;
+      size_t region = use_runs ? grp_run_region(compact, words, cap, gmax_lds, tier != 0) : grp_region(compact, words, cap, gmax_lds, alen);
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       uint32_t wpb = pick_wpb(region);
       TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
+      if (use_runs) {
+        using run_kernel_t = void (*)(const uint32_t *, uint32_t, Csr, Csr, const uint32_t *, RowMeta, NumOut, uint32_t, uint32_t, uint32_t, uint32_t);
+#define SG_RUN_ROW(W, C, G, T) {k_num_grp_run<W, C, 3, G, T>, k_num_grp_run<W, C, 5, G, T>, k_num_grp_run<W, C, 8, G, T>}
+#define SG_RUN_G(C, T) {SG_RUN_ROW(false, C, 3, T), SG_RUN_ROW(false, C, 5, T), SG_RUN_ROW(false, C, 8, T)}
+        // [cap 128 / 512][flat / two-level bitmap][rows of A per group][rows of B per run]
+        static const run_kernel_t narrow[2][2][3][3] = {{SG_RUN_G(false, 2), SG_RUN_G(true, 2)}, {SG_RUN_G(false, 8), SG_RUN_G(true, 8)}};
+        static const run_kernel_t wide[2][2][3] = {{SG_RUN_ROW(true, false, 3, 8), SG_RUN_ROW(true, false, 4, 8)},
+                                                   {SG_RUN_ROW(true, true, 3, 8), SG_RUN_ROW(true, true, 4, 8)}};
+#undef SG_RUN_G
+#undef SG_RUN_ROW
+        const run_kernel_t kern = tier ? wide[compact ? 1 : 0][gsel][rsel] : narrow[cap <= 128 ? 0 : 1][compact ? 1 : 0][gsel][rsel];
+        // groups a wavefront takes one after the other: as many as leave 16 wavefronts of work per slot of the device
+        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->grp_rpw, cnt / ((uint64_t)ctx->cu_count * 32 * 16)));
+        hipLaunchKernelGGL(kern, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB,
+                           rowinfo_of(B).same, rm, no, words, cap, wpb, rpw);
+      } else {
       auto kern = compact ? (tier == 0 ? k_num_window_grp<0, true> : tier == 1 ? k_num_window_grp<1, true> : k_num_window_grp<2, true>)
                           : (tier == 0 ? k_num_window_grp<0, false> : tier == 1 ? k_num_window_grp<1, false> : k_num_window_grp<2, false>);
       if (walk_tail(ctx, B))
@@ -1406,6 +1455,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       hipLaunchKernelGGL(kern,
                          dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, no, words, cap, wpb, gmax);
+      }
     } else if (key >= NUM_HASH0 && key < NUM_GLOBAL && (key & 3) == 0) { // short rows
       const uint32_t log2pm = 6 + ((uint32_t)(key - NUM_HASH0) >> 2);
       // 32-bit table entries (column << log2pm | product number) when every column fits beside the number
@@ -1518,6 +1568,14 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (hc->total_nprod) return fail(SPGEMM_ERR_STATE, "internal: the big-row numeric kernel met a damaged work list");
+#ifdef SG_GRP_STAMPS
+  {
+    unsigned long long ph[8];
+    HIP_TRY(hipMemcpy(ph, zero_count + 8, sizeof(ph), hipMemcpyDeviceToHost));
+    fprintf(stderr, "grp_run stamps (Mticks, all waves): row state of the wave's groups %.1f wait for description %.1f bitmap set-up %.1f units %.1f write-out %.1f\n",
+            ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6);
+  }
+#endif
 #ifdef SG_SLICE_STAMPS
   {
     unsigned long long ph[20];
