@@ -129,6 +129,10 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   identical A rows, of the big-row kernels (B sorted)
  *   big_win_words                                   bitmap window of the big-row symbolic kernel
  *                                                   (32-column words, multiple of 1024, <= 32768)
+ *   big_sym_bounds                                  1 (default): for a B of at most 16 such windows the big-row
+ *                                                   symbolic kernel takes the pieces of B's rows per window
+ *                                                   from bounds computed once per B (no cursors, independent
+ *                                                   loads); 0: it walks every row from a cursor
  *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)
  *   slice_queues                                    1..8 work queues of that kernel (workgroup b starts
  *                                                   on queue b mod queues: 8 = one queue per XCD)

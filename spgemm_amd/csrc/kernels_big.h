@@ -257,6 +257,215 @@ __global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_e
   }
 }
 
+// ---- symbolic, big rows, with the window bounds of B's rows known ----------------------------------------
+// k_sym_big finds the piece of a B row that falls into a bitmap window by walking the row from a
+// cursor, one dependent load after the other; the rows of B that matter here are long, and one step
+// of 512 entries per workgroup in flight leaves the kernel waiting for memory most of the time.
+// For a B with at most BIG2_MAX_WIN windows of 2^ws columns, the position of the first entry of
+// every row of B in every window is computed once per B (k_b_winbounds: wb[k * (nwin + 1) + w],
+// relative to the row's start; wb[k][nwin] = the row's length).  The pieces of a window are then
+// known before a single column is loaded: a batch of up to BIG_THREADS entries of the A row gives
+// their lengths, a prefix sum lays the batch's products end to end, and thread x takes the products
+// x, x + BIG_THREADS, ... - FOUR of them in flight, none of their loads depending on another.
+// The write-out of the window's bitmap is k_sym_big's.
+constexpr uint32_t BIG2_MAX_WIN = 16;
+__global__ void __launch_bounds__(256)
+    k_b_winbounds(uint64_t rows, const uint64_t *__restrict__ b_ptr, const uint32_t *__restrict__ b_col, uint32_t nwin,
+                  uint32_t ws, uint32_t *__restrict__ wb) {
+  // one thread per (row, window boundary 1..nwin-1); boundary 0 is 0 and boundary nwin the row's length
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t row = i / (nwin + 1u);
+  const uint32_t w = (uint32_t)(i % (nwin + 1u));
+  if (row >= rows) return;
+  const uint64_t b0 = b_ptr[row], b1 = b_ptr[row + 1];
+  uint64_t lo = b0, hi = b1;
+  if (w == 0) hi = b0;
+  else if (w == nwin) lo = b1;
+  const uint64_t key = (uint64_t)w << ws;
+  while (lo < hi) { // first entry whose column is >= key (the row is sorted)
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if ((uint64_t)b_col[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  wb[i] = (uint32_t)(lo - b0);
+}
+
+__host__ __device__ inline size_t sym_big2_lds(uint32_t win_words) {
+  return (size_t)win_words * 4 + (size_t)BIG_THREADS * (8 + 4) + 16 + (size_t)(win_words / 64) * 4;
+}
+#ifdef SG_SYM2_STAMPS
+// diagnostic build: cycles per phase of k_sym_big2, summed over the wavefronts
+__device__ unsigned long long g_big2_stamps[8];
+#define BIG2_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define BIG2_STAMP(i) do { } while (0)
+#endif
+__global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(2 * BIG_WAVES / 4, 2 * BIG_WAVES / 4)))
+    k_sym_big2(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, const uint32_t *__restrict__ wb,
+               uint32_t nwin, uint32_t ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t win_words = 1u << (ws - 5u);
+  uint32_t *bits = reinterpret_cast<uint32_t *>(smem);
+  uint64_t *s_base = reinterpret_cast<uint64_t *>(smem + (size_t)win_words * 4);
+  uint32_t *s_pre = reinterpret_cast<uint32_t *>(s_base + BIG_THREADS); // exclusive prefix of the batch's piece lengths (+ total)
+  uint32_t *s_blk = s_pre + BIG_THREADS + 4;
+  __shared__ uint64_t s_wave[BIG_WAVES];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const uint32_t row = scalar_view(rows)[blockIdx.x];
+  const uint64_t a0 = scalar_view(A.ptr)[row], a1 = scalar_view(A.ptr)[row + 1];
+  const uint32_t len_a = (uint32_t)min(a1 - a0, (uint64_t)0xFFFFFFFFu);
+  const uint32_t cmin = m.cmin[row], cmax = m.cmax[row];
+  uint32_t *out = m.temp_cols + m.t_off[row];
+  uint32_t carry = 0;
+#ifdef SG_SYM2_STAMPS
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+  for (uint32_t w = tid * 4u; w < win_words; w += BIG_THREADS * 4u)
+    *reinterpret_cast<uint4 *>(&bits[w]) = make_uint4(0u, 0u, 0u, 0u);
+  // A row of up to BIG_THREADS entries (one per thread) keeps its entry's B row in registers and
+  // fetches the bounds of the NEXT window while this one is walked: nothing of the row's own
+  // description is waited for inside a window.
+  const bool one_batch = len_a <= BIG_THREADS;
+  const uint32_t win0 = cmin >> ws, win1 = cmax >> ws;
+  uint64_t my_b0 = 0;
+  const uint32_t *my_wb = wb; // (a valid address for the threads without an entry)
+  bool have = false;
+  uint32_t o_lo = 0, o_hi = 0; // bounds of my B row in the current window
+  if (one_batch && tid < len_a) {
+    const uint32_t k = A.col[a0 + tid];
+    my_b0 = B.ptr[k];
+    my_wb = wb + (size_t)k * (nwin + 1u);
+    have = true;
+    o_lo = my_wb[win0];
+    o_hi = my_wb[win0 + 1u];
+  }
+  for (uint32_t win = win0; win <= win1; ++win) {
+    // words of this window that can hold an output of the row
+    const uint32_t wlo = max(win << (ws - 5u), cmin >> 5), whi = min(((win + 1u) << (ws - 5u)) - 1u, cmax >> 5);
+    const uint32_t nw = whi - wlo + 1u;
+    const uint32_t nblk = (nw + 255u) >> 8;
+    uint32_t o_next = o_hi;
+    if (one_batch && have && win < win1) o_next = my_wb[win + 2u]; // end of my piece in the next window: lands during this one
+    for (uint32_t kb = 0; kb < len_a; kb += BIG_THREADS) {
+      // the pieces of this batch of A entries in this window
+      const uint32_t t = kb + tid;
+      uint32_t plen = 0;
+      uint64_t base = 0;
+      if (one_batch) {
+        plen = o_hi - o_lo;
+        base = my_b0 + o_lo;
+      } else if (t < len_a) {
+        const uint32_t k = A.col[a0 + t];
+        const uint32_t *wk = wb + (size_t)k * (nwin + 1u) + win;
+        const uint32_t o0 = wk[0], o1 = wk[1];
+        plen = o1 - o0;
+        base = B.ptr[k] + o0;
+      }
+      uint64_t total64;
+      const uint32_t excl = (uint32_t)block_excl_scan64(plen, s_wave, &total64); // (two barriers inside: the batch before is done with s_pre / s_base)
+      s_pre[tid] = excl;
+      s_base[tid] = base;
+      if (tid == 0) s_pre[BIG_THREADS] = (uint32_t)total64;
+      __syncthreads();
+      BIG2_STAMP(0);
+      const uint32_t total = (uint32_t)total64; // (a batch holds fewer than 2^32 products: 512 pieces of a window of 2^19 columns)
+      // entry whose piece holds product q: the last one whose prefix is <= q (pieces of length 0 share a prefix with their successor)
+      auto entry_of = [&](uint32_t q) {
+        uint32_t e = 0;
+#pragma unroll
+        for (uint32_t sft = BIG_THREADS / 2; sft > 0; sft >>= 1)
+          if (s_pre[e + sft] <= q) e += sft;
+        return e;
+      };
+      constexpr int NF = 8; // products of a thread whose loads are in flight together
+      for (uint32_t q0 = 0; q0 < total; q0 += BIG_THREADS * NF) {
+        uint32_t c[NF];
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+          const uint32_t q = q0 + (uint32_t)u * BIG_THREADS + tid;
+          c[u] = EMPTY_KEY;
+          if (q < total) {
+            const uint32_t e = entry_of(q);
+            c[u] = B.col[s_base[e] + (q - s_pre[e])];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u)
+          if (c[u] != EMPTY_KEY) atomicOr(&bits[(c[u] >> 5) - wlo], 1u << (c[u] & 31u));
+      }
+      BIG2_STAMP(1);
+      __syncthreads(); // every piece of the batch is in the bitmap; s_pre / s_base may be rewritten
+      BIG2_STAMP(2);
+    }
+    o_lo = o_hi;
+    o_hi = o_next;
+    // set bits per block of 256 words (four per lane); the words move to registers for the
+    // write-out and the bitmap is cleared for the next window
+    uint4 wd[BIG_BPW];
+    uint32_t ex[BIG_BPW];
+#pragma unroll
+    for (uint32_t i = 0; i < BIG_BPW; ++i) {
+      const uint32_t b = wv + BIG_WAVES * i;
+      wd[i] = make_uint4(0u, 0u, 0u, 0u);
+      ex[i] = 0u;
+      if (b < nblk) { // wave-uniform
+        uint4 *src = reinterpret_cast<uint4 *>(&bits[b * 256u + lane * 4u]);
+        wd[i] = *src;
+        const uint32_t pc = __popc(wd[i].x) + __popc(wd[i].y) + __popc(wd[i].z) + __popc(wd[i].w);
+        uint32_t incl = 0;
+        if (__ballot(pc != 0u)) {
+          incl = group_incl_scan<64>(pc);
+          *src = make_uint4(0u, 0u, 0u, 0u);
+        }
+        ex[i] = incl - pc;
+        if (lane == 63) s_blk[b] = incl;
+      }
+    }
+    BIG2_STAMP(3);
+    __syncthreads();
+    BIG2_STAMP(4);
+    // every wavefront scans the block totals for itself (nblk <= 128: two per lane)
+    const uint32_t t0 = 2u * lane < nblk ? s_blk[2u * lane] : 0u;
+    const uint32_t t1 = 2u * lane + 1u < nblk ? s_blk[2u * lane + 1u] : 0u;
+    const uint32_t pair_incl = group_incl_scan<64>(t0 + t1);
+    const uint32_t tot = group_last<64>(pair_incl);
+    const uint32_t pair_excl = pair_incl - (t0 + t1); // offset of block 2 * lane
+#pragma unroll
+    for (uint32_t i = 0; i < BIG_BPW; ++i) {
+      const uint32_t b = wv + BIG_WAVES * i;
+      if (b >= nblk) break;
+      const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)pair_excl, (int)(b >> 1)) +
+                            ((b & 1u) ? (uint32_t)__builtin_amdgcn_readlane((int)t0, (int)(b >> 1)) : 0u);
+      uint32_t *dst = out + carry + boff; // (wave-uniform)
+      const uint32_t cbase = (wlo + b * 256u + lane * 4u) << 5;
+      const uint32_t w4[4] = {wd[i].x, wd[i].y, wd[i].z, wd[i].w};
+      // every lane stores the columns of its own four words
+      uint32_t at = ex[i];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        uint32_t word = w4[j];
+        while (word) {
+          dst[at++] = cbase + 32u * j + (uint32_t)__ffs(word) - 1u;
+          word &= word - 1u;
+        }
+      }
+    }
+    BIG2_STAMP(5);
+    carry += tot;
+    __syncthreads(); // s_blk is reused by the next window
+    BIG2_STAMP(6);
+  }
+  if (tid == 0) {
+    m.nnz[row] = carry;
+    m.num_key[row] = (uint8_t)num_key_of(m.sym_key[row], carry, m.hash_num_max);
+  }
+#ifdef SG_SYM2_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_big2_stamps[i], tph[i]);
+#endif
+}
+
 // ---- numeric, big rows: slices of the output row, one wavefront per slice ---------------------------
 // Needs B rows with strictly increasing columns.  The sorted structural columns of a big row are
 // cut into chunks of SLICE_W outputs; a work item is a run of consecutive chunks of one row and is

@@ -67,6 +67,9 @@ struct spgemm_mat {
   uint64_t prec_slots = 0;    // record slots in d_prec; the padded column array follows them
   Rec12 *d_packed = nullptr;  // the entries as 12-byte records {column, value}, read by the big-row numeric kernel (option)
   size_t bytes_packed = 0;
+  uint32_t *d_wb = nullptr;   // big-row symbolic kernel: first entry of every row in every window of 2^wb_ws columns (k_b_winbounds)
+  size_t bytes_wb = 0;
+  uint32_t wb_nwin = 0, wb_ws = 0;
   // used by the section helpers of the B exchange, built on first use, dropped by spgemm_mat_invalidate:
   std::vector<uint64_t> h_ptr;  // host copy of the row pointer
   uint32_t *d_rowlen = nullptr; // row lengths as uint32 (what travels in the exchange)
@@ -120,6 +123,7 @@ struct spgemm_ctx {
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
+  uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
   uint32_t grp_rpw = 8;          // most groups one wavefront of the run kernel takes one after the other (<= 64)
   int cu_count = 256;
@@ -393,6 +397,37 @@ static int ensure_packed(spgemm_ctx *ctx, const spgemm_mat *B) {
   return SPGEMM_OK;
 }
 
+// Window bounds of B's rows for the big-row symbolic kernel (k_sym_big2): windows of 2^ws columns, as
+// wide as the bitmap allows (win_words_max 32-column words) and at most BIG2_MAX_WIN of them; a wider
+// B has none (*ok = false: the cursor-walking kernel takes its big rows).  Built when that kernel
+// first needs them, kept on the handle like the row info.  B's rows must be sorted.
+static int ensure_winbounds(spgemm_ctx *ctx, const spgemm_mat *B, uint32_t win_words_max, bool *ok) {
+  uint32_t ws = 5;
+  while ((1u << (ws - 5u)) < win_words_max && ws < 19u) ++ws; // the widest window the bitmap holds
+  if ((1u << (ws - 5u)) > win_words_max) --ws;
+  const uint64_t nwin = B->cols ? ((B->cols - 1) >> ws) + 1 : 1;
+  *ok = ws >= 10u && nwin <= BIG2_MAX_WIN && B->rows > 0;
+  if (!*ok) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  if (B->d_wb && B->wb_ws == ws && B->wb_nwin == (uint32_t)nwin) return SPGEMM_OK;
+  if (mb->d_wb) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    pool_release(ctx, mb->d_wb, mb->bytes_wb);
+    mb->d_wb = nullptr;
+  }
+  const uint64_t n = B->rows * (nwin + 1);
+  TRY(pool_alloc(ctx, n * 4, (void **)&mb->d_wb, &mb->bytes_wb));
+  mb->wb_ws = ws;
+  mb->wb_nwin = (uint32_t)nwin;
+  for (uint64_t r0 = 0; r0 < B->rows; r0 += (1ull << 24)) { // 2^24 rows per launch keep the grid below 2^32 threads
+    const uint64_t nr = std::min<uint64_t>(B->rows - r0, 1ull << 24);
+    hipLaunchKernelGGL(k_b_winbounds, dim3(div_up_u64(nr * (nwin + 1), 256)), dim3(256), 0, ctx->stream, nr, B->d_ptr + r0, B->d_col,
+                       (uint32_t)nwin, ws, mb->d_wb + r0 * (nwin + 1));
+  }
+  HIP_TRY(hipGetLastError());
+  return SPGEMM_OK;
+}
+
 // Column map of the short-row numeric kernel (entries of B per column range, prefix summed): built
 // when the first launch of that kernel needs it, kept on the handle like the row info.
 static int ensure_colcdf(spgemm_ctx *ctx, const spgemm_mat *B) {
@@ -451,7 +486,7 @@ static void raise_all_lds_limits() { // per device: called with the context's de
   raise_lds_limit(k_sym_hash<true>); raise_lds_limit(k_sym_hash<false>);
   raise_lds_limit(k_num_window<true>); raise_lds_limit(k_num_window<false>);
   raise_lds_limit(k_num_hash<true>); raise_lds_limit(k_num_hash<false>);
-  raise_lds_limit(k_sym_big);
+  raise_lds_limit(k_sym_big); raise_lds_limit(k_sym_big2);
   raise_lds_limit(k_sym_hash_wg<256>); raise_lds_limit(k_sym_hash_wg<512>); raise_lds_limit(k_sym_hash_wg<1024>);
   raise_lds_limit(k_sym_count<4>); raise_lds_limit(k_sym_count<SH_STEPS>);
   raise_lds_limit(k_num_short<4, false>); raise_lds_limit(k_num_short<SH_STEPS, false>);
@@ -750,6 +785,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "walk_tail") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "walk_tail must be 0, 1 or 2");
     ctx->walk_tail = (uint32_t)value;
+  } else if (n == "big_sym_bounds") {
+    if (value > 1) return fail(SPGEMM_ERR_INVALID, "big_sym_bounds must be 0 or 1");
+    ctx->big_sym_bounds = (uint32_t)value;
   } else if (n == "grp_rpw") {
     if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "grp_rpw must be 1..64");
     ctx->grp_rpw = (uint32_t)value;
@@ -953,6 +991,9 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
     if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
     if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
     if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
+    if (m->d_wb) pool_release(ctx, m->d_wb, m->bytes_wb);
+    m->d_wb = nullptr;
+    m->bytes_wb = 0;
     m->d_rowinfo = nullptr;
     m->d_colcdf = nullptr;
     m->d_packed = nullptr;
@@ -972,6 +1013,7 @@ static void release_mat(spgemm_ctx *ctx, spgemm_mat *m) {
   if (m->d_packed) pool_release(ctx, m->d_packed, m->bytes_packed);
   if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
   if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
+  if (m->d_wb) pool_release(ctx, m->d_wb, m->bytes_wb);
   if (m->d_rowlen) pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
   if (m->owns) {
     pool_release(ctx, m->d_ptr, m->bytes_ptr);
@@ -1279,11 +1321,30 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       hipLaunchKernelGGL(flat ? k_sym_hash<true> : k_sym_hash<false>, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, log2s);
     } else if (b_sorted && ctx->big_rows) {
+      bool bounds = false;
+      if (ctx->big_sym_bounds) TRY(ensure_winbounds(ctx, B, std::min<uint32_t>(ctx->big_win_words, BIG_WIN_MAX), &bounds));
+      st.rows_global += cnt;
+      if (bounds) {
+        // the pieces of B's rows per bitmap window are known in advance: no cursors, independent loads
+        const uint32_t win_words = 1u << (B->wb_ws - 5u);
+        const size_t lds = sym_big2_lds(win_words);
+        TRY(prof_begin(ctx, 0, 4, BIG_THREADS, cnt, win_words, 1, lds, rows_bin));
+        hipLaunchKernelGGL(k_sym_big2, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, B->d_wb,
+                           B->wb_nwin, B->wb_ws);
+#ifdef SG_SYM2_STAMPS
+        {
+          unsigned long long ph[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          HIP_TRY(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_big2_stamps), sizeof(ph)));
+          HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_big2_stamps), zero, sizeof(zero)));
+          fprintf(stderr, "sym_big2 stamps (Mcycles, all waves): pieces+scan %.1f walk %.1f barrier %.1f popcount %.1f barrier %.1f write %.1f barrier %.1f\n",
+                  ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6);
+        }
+#endif
+      } else {
       // windows of up to 2^20 columns (128 KiB of LDS); a narrower matrix gets one window
       uint32_t win_words = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(ctx->big_win_words, BIG_WIN_MAX), align_up((B->cols + 31) / 32, BIG_THREADS));
       size_t lds = sym_big_lds(win_words);
       if (A->nnz > BIG_CUR) TRY(grow(ctx, ctx->big_cur, A->nnz * 16));
-      st.rows_global += cnt;
       TRY(prof_begin(ctx, 0, 4, BIG_THREADS, cnt, win_words, 0, lds, rows_bin));
       unsigned long long *sym_stamps = reinterpret_cast<unsigned long long *>(ctx->d_small) + 32; // diagnostic builds only
 #ifdef SG_SYM_STAMPS
@@ -1301,6 +1362,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
                 ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6);
       }
 #endif
+      }
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_sym);
