@@ -4,12 +4,15 @@
 //   dphpc_amd <algo> <matrix> <run_path> <n_runs> <n_warmup> <shuffle> <partition>
 //             <parallel_load> <persist> <matrix_path>
 //             [--ranks P] [--gpus G] [--impl baseline|drop|shuffle] [--sections N] [--seed S] [--shuffle-iterations I] [--relabel result|b]
+//             [--stages S]
 //
 // <algo>: baseline | outer (no section dropping) | drop | drop_parallel | drop_at_once |
 //         drop_at_once_parallel (bitmap-filtered exchange).  All run the same GPU operator; the
 //         name only selects whether the bitmap is used.  `full` and `comb` are not built.
 // --impl overrides <algo>/<shuffle>: baseline = no drop, no shuffle; drop = bitmap; shuffle =
 //         bitmap + random row/column shuffle.
+// --stages S: the pipelined schedule: every rank cuts its rows into S blocks and exchanges the B sections
+//         of block s + 1 while block s is multiplied (HipOptions::stages).
 // The P ranks live in this one process (rank r on GPU r % G); the reference starts P MPI ranks.
 // Files written to <run_path>: algo, matrix, partitions.csv, A_shuffle, B_shuffle, C_<rank>.mtx,
 // measurements_<rank>.csv: the layout the reference's scripts read.
@@ -33,7 +36,7 @@ int main(int argc, char **argv) {
   try {
     std::vector<std::string> pos;
     int n_ranks = 0, n_gpus = 0;
-    uint32_t n_sections = 512;
+    uint32_t n_sections = 512, n_stages = 1;
     uint64_t seed = 1;
     std::string relabel_where;         // "", "result" or "b": where a column shuffle is applied
     uint32_t shuffle_iterations = 20; // of the iterative shuffle (the reference stops on wall clock)
@@ -51,6 +54,7 @@ int main(int argc, char **argv) {
       else if (a == "--seed") seed = std::stoull(next());
       else if (a == "--shuffle-iterations") shuffle_iterations = (uint32_t)std::stoul(next());
       else if (a == "--relabel") relabel_where = next();
+      else if (a == "--stages") n_stages = (uint32_t)std::stoul(next());
       else pos.push_back(a);
     }
     if (pos.size() < 10) {
@@ -122,7 +126,8 @@ int main(int argc, char **argv) {
     partition::save_shuffle(B_shuffle, run_path + "/B_shuffle");
     std::cout << "SHUFFLING FINISHED!" << std::endl;
 
-    communication::World world(n_nodes, n_gpus);
+    if (n_stages < 1 || n_stages > 64) { std::cerr << "--stages takes 1..64\n"; return 1; }
+    communication::World world(n_nodes, n_gpus, n_stages > 1);
 
     // partitions (reference src/main.cpp:176-199)
     std::cout << "Computing \"" << partitioning_algo << "\" partitioning" << std::endl;
@@ -146,7 +151,7 @@ int main(int argc, char **argv) {
     if (persist_results) partition::save_partitions(partitions, run_path + "/partitions.csv");
 
     // operators, one per rank (reference src/main.cpp:223-310)
-    mults::HipOptions opt{drop, n_sections, mults::product_rows_are_narrow(tA, *tB)};
+    mults::HipOptions opt{drop, n_sections, mults::product_rows_are_narrow(tA, *tB), n_stages};
     if (relabel_where == "result") opt.relabel_result = true;
     else if (relabel_where == "b") opt.relabel_result = false;
     else if (!relabel_where.empty()) { std::cerr << "--relabel takes result or b\n"; return 1; }
@@ -156,10 +161,8 @@ int main(int argc, char **argv) {
       mult[rank] = std::make_unique<mults::HipSpgemm>(rank, n_nodes, partitions, tA, &keep_rows, *tB, &B_shuffle, world, opt);
     }
     // "Allgather" of the bitmaps and "Alltoall" of the filtered sizes
-    std::vector<std::vector<bool>> bitmaps(n_nodes);
-    for (int r = 0; r < n_nodes; ++r) bitmaps[r] = mult[r]->bitmap;
     std::vector<std::vector<size_t>> sizes_from(n_nodes, std::vector<size_t>(n_nodes));
-    for (int r = 0; r < n_nodes; ++r) mult[r]->bitmaps = bitmaps;
+    for (int r = 0; r < n_nodes; ++r) mult[r]->share_bitmaps(mult);
     for (int r = 0; r < n_nodes; ++r) {
       auto s = mult[r]->get_B_serialization_sizes();
       for (int d = 0; d < n_nodes; ++d) sizes_from[d][r] = s[d];
@@ -185,9 +188,10 @@ int main(int argc, char **argv) {
           }
         }
       } catch (const std::exception &e) {
+        // The other ranks may be waiting for this one: call the meetings off (they give up at
+        // their next one, with an error of their own) instead of ending the process under them.
         failure[r] = e.what();
-        std::cerr << "rank " << r << ": " << e.what() << std::endl;
-        std::exit(1); // the other ranks wait in a barrier: end the process, as MPI_Abort would
+        world.abandon();
       }
     };
     const auto t_start = std::chrono::steady_clock::now();
@@ -197,6 +201,16 @@ int main(int argc, char **argv) {
       for (auto &t : threads) t.join();
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    bool failed = false;
+    for (int r = 0; r < n_nodes; ++r)
+      if (!failure[r].empty()) {
+        std::cerr << "rank " << r << ": " << failure[r] << std::endl;
+        failed = true;
+      }
+    if (failed) {
+      mult.clear(); // the operators go before the world they live in
+      return 1;
+    }
     printf("ranks %d: %d runs (%d warm-up) in %.3f ms wall, %.3f ms per run\n", n_nodes, n_warmup + n_runs, n_warmup, wall_ms,
            wall_ms / std::max(1, n_warmup + n_runs));
     measure_point(0, measure::global, measure::MeasurementEvent::END);

@@ -17,10 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "spgemm_amd", "dphpc_amd")
 
 
-def run_driver(tmp_path, algo, matrix, shuffle="none", part="naive", extra=()):
+def driver_cmd(tmp_path, algo, matrix, shuffle="none", part="naive", extra=()):
     run = tmp_path / f"run_{algo}_{matrix}_{shuffle}_{'_'.join(extra)}"
-    cmd = [DRIVER, algo, matrix, str(run), "2", "1", shuffle, part, "false", "true",
-           os.path.join(ROOT, "tests", "golden"), *extra]
+    return run, [DRIVER, algo, matrix, str(run), "2", "1", shuffle, part, "false", "true",
+                 os.path.join(ROOT, "tests", "golden"), *extra]
+
+
+def run_driver(tmp_path, algo, matrix, shuffle="none", part="naive", extra=()):
+    run, cmd = driver_cmd(tmp_path, algo, matrix, shuffle, part, extra)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     return run, p.stdout
@@ -110,3 +114,35 @@ def test_column_shuffle_applied_to_result_or_to_b(tmp_path, golden_dir, where):
                         extra=("--ranks", "3", "--sections", "4", "--relabel", where))
     M, _, _ = merged(run, 3, 165, 165)
     orc.assert_same(to_o(M), orc.read_mtx(f"{golden_dir}/ref_first/C_expected.mtx"), rtol=0.0)
+
+
+@pytest.mark.parametrize("ranks,stages,algo,shuffle", [(4, 3, "drop_parallel", "none"), (2, 5, "baseline", "none"),
+                                                       (3, 2, "drop", "random")])
+def test_staged_schedule_gives_the_same_result(tmp_path, golden_dir, ranks, stages, algo, shuffle):
+    """--stages S: every rank cuts its rows into S blocks and exchanges the sections of block s + 1
+    while block s is multiplied; the merged result is the reference's C, entry for entry."""
+    run, out = run_driver(tmp_path, algo, "ref_first", shuffle=shuffle,
+                          extra=("--ranks", str(ranks), "--sections", "4", "--stages", str(stages)))
+    M, parts, Cs = merged(run, ranks, 165, 165)
+    orc.assert_same(to_o(M), orc.read_mtx(f"{golden_dir}/ref_first/C_expected.mtx"), rtol=0.0)
+    if shuffle == "none" and ranks == 4:
+        assert [c.nnz for c in Cs] == [182, 600, 759, 1526]               # as the unstaged run
+        # a rank's bitmap is the union of its blocks': the same sections as the unstaged run drops
+        got = sorted(float(l.split(":")[1]) for l in out.splitlines() if l.startswith("Bitmap drop percentage"))
+        assert got == sorted([0.75, 0.5, 0.25, 0.0])
+    for r in range(ranks):
+        with open(run / f"measurements_{r}.csv") as f:
+            funcs = {x[0] for x in csv.reader(f)}
+        assert {"gemm", "mult", "wait_all", "filter", "deserialize"} <= funcs
+
+
+@pytest.mark.parametrize("stages", [1, 2])
+def test_a_failing_rank_ends_the_run_with_an_error(tmp_path, stages):
+    """A rank that gives up inside a run does not leave the others waiting: the process ends with
+    exit status 1 and the rank's message, and writes no result."""
+    run, cmd = driver_cmd(tmp_path, "drop_parallel", "ref_first", extra=("--ranks", "3", "--sections", "4", "--stages", str(stages)))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, DPHPC_AMD_FAIL_RANK="1"))
+    assert p.returncode == 1, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "rank 1: failure requested through DPHPC_AMD_FAIL_RANK" in p.stderr
+    assert "another rank failed" in p.stderr            # the two others were told
+    assert not (run / "C_0.mtx").exists()
