@@ -344,6 +344,17 @@ int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, co
 /* Host bytes into a device buffer of the context (set-up data such as a column permutation;
  * returns when the copy is done). */
 int spgemm_buffer_upload(spgemm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+/* The receive side of the reference's exchange for a B that stays on the device: the n CSR
+ * sections of a received blocked blob (BlockedCSRMatrix(const Data &), include/matrix_impl.hpp:
+ * 428-439, 480-485: per section a row pointer of rows[i] + 1 uint32 that starts at 0, nnz[i]
+ * columns, nnz[i] values; the values may be aligned to 4 bytes only) go to the device in the layout
+ * spgemm_pack_sections produces and spgemm_assemble_row_ptr reads: row lengths, columns and values
+ * of the sections one after the other.  All pointers but the d_* ones are HOST pointers; the
+ * sections come in ascending order.  Returns when the host arrays may be reused. */
+int spgemm_upload_sections(spgemm_ctx *ctx, uint32_t n, const uint32_t *const *h_row_ptr,
+                           const uint32_t *const *h_col_idx, const void *const *h_val,
+                           const uint32_t *rows, const uint32_t *nnz, uint32_t *d_row_len_out,
+                           uint32_t *d_col_idx_out, double *d_val_out);
 
 #ifdef __cplusplus
 }

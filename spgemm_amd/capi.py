@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "spgemm_partition_naive", "spgemm_partition_balanced", "spgemm_row_nprod",
     "spgemm_shuffle_random", "spgemm_shuffle_iterative", "spgemm_mat_select", "spgemm_mat_relabel_columns",
     "spgemm_section_nnz", "spgemm_pack_sections", "spgemm_assemble_row_ptr", "spgemm_assemble_row_ptr_noalloc",
-    "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy", "spgemm_buffer_upload",
+    "spgemm_buffer_alloc", "spgemm_buffer_free", "spgemm_buffer_copy", "spgemm_buffer_upload", "spgemm_upload_sections",
 ]
 
 
@@ -134,6 +134,7 @@ def load() -> ctypes.CDLL:
         "spgemm_assemble_row_ptr_noalloc": (i32, [vp, u64, u32, vp, vp, u64, vp, ctypes.POINTER(u64)]),
         "spgemm_buffer_copy": (i32, [vp, vp, vp, vp, ctypes.c_size_t]),
         "spgemm_buffer_upload": (i32, [vp, vp, vp, ctypes.c_size_t]),
+        "spgemm_upload_sections": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

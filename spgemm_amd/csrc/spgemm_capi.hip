@@ -2229,6 +2229,41 @@ extern "C" int spgemm_buffer_upload(spgemm_ctx *ctx, void *d_dst, const void *h_
   return SPGEMM_OK;
 }
 
+extern "C" int spgemm_upload_sections(spgemm_ctx *ctx, uint32_t n, const uint32_t *const *h_row_ptr,
+                                      const uint32_t *const *h_col_idx, const void *const *h_val, const uint32_t *rows,
+                                      const uint32_t *nnz, uint32_t *d_row_len_out, uint32_t *d_col_idx_out,
+                                      double *d_val_out) {
+  if (!ctx || (n && (!h_row_ptr || !h_col_idx || !h_val || !rows || !nnz))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
+  uint64_t rows_total = 0, nnz_total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!h_row_ptr[i] || (nnz[i] && (!h_col_idx[i] || !h_val[i]))) return fail(SPGEMM_ERR_INVALID, "section %u: NULL array", i);
+    if (h_row_ptr[i][0] != 0 || h_row_ptr[i][rows[i]] != nnz[i])
+      return fail(SPGEMM_ERR_INVALID, "section %u: its row pointer does not run from 0 to its entry count", i);
+    rows_total += rows[i];
+    nnz_total += nnz[i];
+  }
+  if ((rows_total && !d_row_len_out) || (nnz_total && (!d_col_idx_out || !d_val_out))) return fail(SPGEMM_ERR_INVALID, "NULL output buffer");
+  TRY(set_device(ctx));
+  // the row lengths of all sections in one piece (the blob holds row pointers), then one copy per array and section
+  std::vector<uint32_t> len(rows_total);
+  uint64_t ro = 0, zo = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t r = 0; r < rows[i]; ++r) {
+      if (h_row_ptr[i][r + 1] < h_row_ptr[i][r]) return fail(SPGEMM_ERR_INVALID, "section %u: row pointer decreases at row %u", i, r);
+      len[ro + r] = h_row_ptr[i][r + 1] - h_row_ptr[i][r];
+    }
+    if (nnz[i]) {
+      HIP_TRY(hipMemcpyAsync(d_col_idx_out + zo, h_col_idx[i], (size_t)nnz[i] * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(d_val_out + zo, h_val[i], (size_t)nnz[i] * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ro += rows[i];
+    zo += nnz[i];
+  }
+  if (rows_total) HIP_TRY(hipMemcpyAsync(d_row_len_out, len.data(), rows_total * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SPGEMM_OK;
+}
+
 extern "C" int spgemm_buffer_copy(spgemm_ctx *dst_ctx, void *d_dst, spgemm_ctx *src_ctx, const void *d_src, size_t bytes) {
   if (!dst_ctx || !src_ctx || (bytes && (!d_dst || !d_src))) return fail(SPGEMM_ERR_INVALID, "NULL argument");
   if (!bytes) return SPGEMM_OK;
