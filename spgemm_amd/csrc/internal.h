@@ -18,4 +18,8 @@ void spgemm_internal_pool_release(spgemm_ctx *ctx, void *p, size_t got);
 // (the scratch the sort needs) is set.
 int spgemm_internal_sort_records12(hipStream_t stream, const uint32_t *key_in, uint32_t *key_out, const void *rec_in,
                                    void *rec_out, size_t n, void *tmp, size_t *tmp_bytes);
+// every row of a CSR structure (row pointer m_ptr) sorted by the 32-bit keys of its entries (all below
+// key_limit), stable, values moving along: key_in / val_in -> key_out / val_out; drains the stream
+int spgemm_internal_sort_rows(spgemm_ctx *ctx, uint64_t rows, uint64_t nnz, uint64_t key_limit, const uint64_t *m_ptr,
+                              const uint32_t *key_in, uint32_t *key_out, const double *val_in, double *val_out);
 }

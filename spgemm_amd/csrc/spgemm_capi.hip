@@ -1968,12 +1968,27 @@ extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uin
   }
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 4, (void **)&R->d_col, &R->bytes_col);
   if (rc == SPGEMM_OK) rc = pool_alloc(ctx, nnz * 8, (void **)&R->d_val, &R->bytes_val);
+  // Rows that have to be sorted by their new column ids are copied into scratch arrays first and
+  // sorted from there into the result (segmented radix sort on the device, stable).
+  const bool sorting = sort_rows && nnz && n_out;
+  uint32_t *t_col = nullptr;
+  double *t_val = nullptr;
+  size_t t_col_got = 0, t_val_got = 0;
+  if (rc == SPGEMM_OK && sorting) rc = pool_alloc(ctx, nnz * 4, (void **)&t_col, &t_col_got);
+  if (rc == SPGEMM_OK && sorting) rc = pool_alloc(ctx, nnz * 8, (void **)&t_val, &t_val_got);
   if (rc == SPGEMM_OK && n_out && nnz) {
     hipLaunchKernelGGL(k_select_copy, dim3(div_up_u64(n_out * 64, 256)), dim3(256), 0, ctx->stream, n_out, kr, M->d_ptr,
-                       M->d_col, M->d_val, cn, (const uint64_t *)R->d_ptr, R->d_col, R->d_val);
+                       M->d_col, M->d_val, cn, (const uint64_t *)R->d_ptr, sorting ? t_col : R->d_col, sorting ? t_val : R->d_val);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(SPGEMM_ERR_HIP, "select copy failed: %s", hipGetErrorString(e));
+  }
+  if (rc == SPGEMM_OK && sorting)
+    rc = spgemm_internal_sort_rows(ctx, n_out, nnz, cols_out, R->d_ptr, t_col, R->d_col, t_val, R->d_val);
+  if (t_col || t_val) {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (t_col) pool_release(ctx, t_col, t_col_got);
+    if (t_val) pool_release(ctx, t_val, t_val_got);
   }
   if (rc != SPGEMM_OK) {
     std::string keep = g_err;
@@ -1982,41 +1997,6 @@ extern "C" int spgemm_mat_select(spgemm_ctx *ctx, const spgemm_mat *M, const uin
     return rc;
   }
   R->nnz = nnz;
-  if (sort_rows && nnz) {
-    // Sorting rows by the new column ids: pull the matrix to the host, sort each row, push it
-    // back.  Set-up work, done once per operand before any timed multiply.
-    std::vector<uint64_t> ptr(n_out + 1);
-    std::vector<uint32_t> col(nnz);
-    std::vector<double> val(nnz);
-    rc = spgemm_mat_to_host(ctx, R, ptr.data(), col.data(), val.data());
-    if (rc != SPGEMM_OK) {
-      std::string keep = g_err;
-      spgemm_mat_free(ctx, R);
-      g_err = keep;
-      return rc;
-    }
-    std::vector<uint32_t> idx;
-    std::vector<uint32_t> c2;
-    std::vector<double> v2;
-    for (uint64_t r = 0; r < n_out; ++r) {
-      uint64_t j0 = ptr[r], len = ptr[r + 1] - ptr[r];
-      if (len < 2 || std::is_sorted(col.begin() + j0, col.begin() + j0 + len)) continue;
-      idx.resize(len);
-      std::iota(idx.begin(), idx.end(), 0u);
-      std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return col[j0 + a] < col[j0 + b]; });
-      c2.resize(len); v2.resize(len);
-      for (uint64_t t = 0; t < len; ++t) { c2[t] = col[j0 + idx[t]]; v2[t] = val[j0 + idx[t]]; }
-      std::copy(c2.begin(), c2.end(), col.begin() + j0);
-      std::copy(v2.begin(), v2.end(), val.begin() + j0);
-    }
-    hipError_t e = hipMemcpyAsync(R->d_col, col.data(), nnz * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(R->d_val, val.data(), nnz * 8, hipMemcpyHostToDevice, ctx->stream);
-    const hipError_t e2 = hipStreamSynchronize(ctx->stream); // the host vectors die with this scope
-    if (e != hipSuccess || e2 != hipSuccess) {
-      spgemm_mat_free(ctx, R);
-      return fail(SPGEMM_ERR_HIP, "uploading the sorted rows failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-    }
-  }
   *out = R;
   return SPGEMM_OK;
 }

@@ -224,6 +224,88 @@ extern "C" int spgemm_shuffle_iterative(spgemm_ctx *ctx, const spgemm_mat *C, ui
   return SPGEMM_OK;
 }
 
+// Every row of a CSR structure sorted by 32-bit keys (one per entry, below `key_limit`), stable, the
+// values moving with their keys: key_in / val_in -> key_out / val_out (different arrays).  Queued
+// on the context's stream; returns after the stream has drained (the sort's scratch goes back to
+// the pool).
+extern "C" int spgemm_internal_sort_rows(spgemm_ctx *ctx, uint64_t rows, uint64_t nnz, uint64_t key_limit,
+                                         const uint64_t *m_ptr, const uint32_t *key_in, uint32_t *key_out,
+                                         const double *val_in, double *val_out) {
+  hipStream_t st;
+  int rc = spgemm_internal_stream(ctx, &st);
+  if (rc != SPGEMM_OK) return rc;
+  if (!nnz || !rows) return SPGEMM_OK;
+  void *tmp = nullptr;
+  size_t tmp_got = 0;
+  auto fail_out = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+    return code;
+  };
+#define RL_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      std::string m_ = std::string(#expr) + " failed: " + hipGetErrorString(e_);                  \
+      return fail_out(spgemm_internal_fail(SPGEMM_ERR_HIP, m_.c_str()));                          \
+    }                                                                                             \
+  } while (0)
+  {
+    unsigned int end_bit = 1;
+    while (end_bit < 32 && (key_limit - 1) >> end_bit) ++end_bit;
+    // the segmented sort counts entries in 32 bits: ranges of rows of fewer than 2^31 entries each
+    std::vector<uint64_t> cuts{0, rows};
+    if (nnz >= (1ull << 31)) {
+      std::vector<uint64_t> h_ptr(rows + 1);
+      RL_HIP(hipMemcpyAsync(h_ptr.data(), m_ptr, (rows + 1) * 8, hipMemcpyDeviceToHost, st));
+      RL_HIP(hipStreamSynchronize(st));
+      cuts.assign(1, 0);
+      uint64_t r0 = 0;
+      while (r0 < rows) {
+        uint64_t r1 = r0 + 1; // a row of 2^31 entries or more cannot exist: fewer than 2^32 columns... but guard anyway
+        while (r1 < rows && h_ptr[r1 + 1] - h_ptr[r0] < (1ull << 31)) ++r1;
+        if (h_ptr[r1] - h_ptr[r0] >= (1ull << 31)) return fail_out(spgemm_internal_fail(SPGEMM_ERR_UNSUPPORTED, "a row of 2^31 entries or more"));
+        cuts.push_back(r1);
+        r0 = r1;
+      }
+      // the bases of the ranges are needed below
+      std::vector<uint64_t> bases;
+      for (size_t i = 0; i + 1 < cuts.size(); ++i) bases.push_back(h_ptr[cuts[i]]);
+      bases.push_back(nnz);
+      for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        const uint64_t base = bases[i], cnt = bases[i + 1] - base, segs = cuts[i + 1] - cuts[i];
+        if (!cnt) continue;
+        auto offs = rocprim::make_transform_iterator(m_ptr + cuts[i], RelativeOffset{base});
+        size_t need = 0;
+        RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, key_in + base, key_out + base, val_in + base,
+                                                   val_out + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
+        if (need > tmp_got) {
+          RL_HIP(hipStreamSynchronize(st));
+          if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+          tmp = nullptr;
+          rc = spgemm_internal_pool_alloc(ctx, need, &tmp, &tmp_got);
+          if (rc != SPGEMM_OK) return fail_out(rc);
+        }
+        RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, key_in + base, key_out + base, val_in + base,
+                                                   val_out + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
+      }
+    } else {
+      auto offs = rocprim::make_transform_iterator(m_ptr, RelativeOffset{0});
+      size_t need = 0;
+      RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, key_in, key_out, val_in, val_out, (unsigned int)nnz,
+                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
+      rc = spgemm_internal_pool_alloc(ctx, need ? need : 8, &tmp, &tmp_got);
+      if (rc != SPGEMM_OK) return fail_out(rc);
+      RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, key_in, key_out, val_in, val_out, (unsigned int)nnz,
+                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
+    }
+  }
+  RL_HIP(hipStreamSynchronize(st));
+#undef RL_HIP
+  if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
+  return SPGEMM_OK;
+}
+
 // Columns of M renamed by new_id (a device array of M.cols entries, a bijection onto [0, new_cols))
 // and every row sorted by its new column ids, values moving with their columns.  A permutation
 // of the columns commutes with the multiply: (A * B) with the columns of the RESULT renamed equals
@@ -257,12 +339,11 @@ extern "C" int spgemm_mat_relabel_columns(spgemm_ctx *ctx, const spgemm_mat *M, 
   uint64_t *r_ptr = const_cast<uint64_t *>(cr_ptr);
   uint32_t *r_col = const_cast<uint32_t *>(cr_col);
   double *r_val = const_cast<double *>(cr_val);
-  void *keys = nullptr, *tmp = nullptr;
-  size_t keys_got = 0, tmp_got = 0;
+  void *keys = nullptr;
+  size_t keys_got = 0;
   auto fail_out = [&](int code) {
     (void)hipStreamSynchronize(st);
     if (keys) spgemm_internal_pool_release(ctx, keys, keys_got);
-    if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
     spgemm_mat_free(ctx, R);
     return code;
   };
@@ -280,59 +361,13 @@ extern "C" int spgemm_mat_relabel_columns(spgemm_ctx *ctx, const spgemm_mat *M, 
     if (rc != SPGEMM_OK) return fail_out(rc);
     hipLaunchKernelGGL(k_relabel, dim3(blocks_for(nnz)), dim3(256), 0, st, nnz, m_col, d_new_id, static_cast<uint32_t *>(keys));
     RL_HIP(hipGetLastError());
-    unsigned int end_bit = 1;
-    while (end_bit < 32 && (new_cols - 1) >> end_bit) ++end_bit;
-    // the segmented sort counts entries in 32 bits: ranges of rows of fewer than 2^31 entries each
-    std::vector<uint64_t> cuts{0, rows};
-    if (nnz >= (1ull << 31)) {
-      std::vector<uint64_t> h_ptr(rows + 1);
-      RL_HIP(hipMemcpyAsync(h_ptr.data(), m_ptr, (rows + 1) * 8, hipMemcpyDeviceToHost, st));
-      RL_HIP(hipStreamSynchronize(st));
-      cuts.assign(1, 0);
-      uint64_t r0 = 0;
-      while (r0 < rows) {
-        uint64_t r1 = r0 + 1; // a row of 2^31 entries or more cannot exist: fewer than 2^32 columns... but guard anyway
-        while (r1 < rows && h_ptr[r1 + 1] - h_ptr[r0] < (1ull << 31)) ++r1;
-        if (h_ptr[r1] - h_ptr[r0] >= (1ull << 31)) return fail_out(spgemm_internal_fail(SPGEMM_ERR_UNSUPPORTED, "a row of 2^31 entries or more"));
-        cuts.push_back(r1);
-        r0 = r1;
-      }
-      // the bases of the ranges are needed below
-      std::vector<uint64_t> bases;
-      for (size_t i = 0; i + 1 < cuts.size(); ++i) bases.push_back(h_ptr[cuts[i]]);
-      bases.push_back(nnz);
-      for (size_t i = 0; i + 1 < cuts.size(); ++i) {
-        const uint64_t base = bases[i], cnt = bases[i + 1] - base, segs = cuts[i + 1] - cuts[i];
-        if (!cnt) continue;
-        auto offs = rocprim::make_transform_iterator(m_ptr + cuts[i], RelativeOffset{base});
-        size_t need = 0;
-        RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, static_cast<uint32_t *>(keys) + base, r_col + base, m_val + base,
-                                                   r_val + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
-        if (need > tmp_got) {
-          RL_HIP(hipStreamSynchronize(st));
-          if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
-          tmp = nullptr;
-          rc = spgemm_internal_pool_alloc(ctx, need, &tmp, &tmp_got);
-          if (rc != SPGEMM_OK) return fail_out(rc);
-        }
-        RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, static_cast<uint32_t *>(keys) + base, r_col + base, m_val + base,
-                                                   r_val + base, (unsigned int)cnt, (unsigned int)segs, offs, offs + 1, 0, end_bit, st));
-      }
-    } else {
-      auto offs = rocprim::make_transform_iterator(m_ptr, RelativeOffset{0});
-      size_t need = 0;
-      RL_HIP(rocprim::segmented_radix_sort_pairs(nullptr, need, static_cast<uint32_t *>(keys), r_col, m_val, r_val, (unsigned int)nnz,
-                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
-      rc = spgemm_internal_pool_alloc(ctx, need ? need : 8, &tmp, &tmp_got);
-      if (rc != SPGEMM_OK) return fail_out(rc);
-      RL_HIP(rocprim::segmented_radix_sort_pairs(tmp, need, static_cast<uint32_t *>(keys), r_col, m_val, r_val, (unsigned int)nnz,
-                                                 (unsigned int)rows, offs, offs + 1, 0, end_bit, st));
-    }
+    // every row sorted by its new ids, values moving with their columns
+    rc = spgemm_internal_sort_rows(ctx, rows, nnz, new_cols, m_ptr, static_cast<const uint32_t *>(keys), r_col, m_val, r_val);
+    if (rc != SPGEMM_OK) return fail_out(rc);
   }
   RL_HIP(hipStreamSynchronize(st));
 #undef RL_HIP
   if (keys) spgemm_internal_pool_release(ctx, keys, keys_got);
-  if (tmp) spgemm_internal_pool_release(ctx, tmp, tmp_got);
   *out = R;
   return SPGEMM_OK;
 }

@@ -123,8 +123,21 @@ def select_rows(M: HostCsr, keep: np.ndarray) -> HostCsr:
     return HostCsr(len(keep), M.cols, row_ptr, M.col_idx[idx], M.val[idx])
 
 
-def relabel_cols(M: HostCsr, new_id: np.ndarray) -> HostCsr:
-    """Column c becomes new_id[c]; rows are re-sorted by the new ids."""
+def relabel_cols(M: HostCsr, new_id: np.ndarray, ctx=None) -> HostCsr:
+    """Column c becomes new_id[c]; rows are re-sorted by the new ids.  With a device context the
+    renaming and the per-row sort run on the GPU (spgemm_mat_select: a segmented radix sort, seconds
+    instead of a minute at 67 M entries); the result is the same."""
+    if ctx is not None and M.nnz:
+        d = ctx.from_host(M.rows, M.cols, M.row_ptr, M.col_idx, M.val)
+        try:
+            s = ctx.select(d, col_new_id=np.asarray(new_id).astype(np.uint32), new_cols=M.cols, sort_rows=True)
+            try:
+                rp, ci, v = s.to_host()
+            finally:
+                s.free()
+        finally:
+            d.free()
+        return HostCsr(M.rows, M.cols, rp, ci, v)
     c = new_id[M.col_idx.astype(np.int64)]
     order = np.lexsort((c, M.row_ids()))
     return HostCsr(M.rows, M.cols, M.row_ptr.copy(), c[order].astype(np.uint32), M.val[order])
@@ -141,7 +154,7 @@ class RankOperands:
 
 def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partitions: Sequence[Partition],
                         A_shuffle: np.ndarray, B_shuffle: np.ndarray, n_sections: int,
-                        relabel_b: bool = True) -> RankOperands:
+                        relabel_b: bool = True, ctx=None) -> RankOperands:
     """relabel_b=False leaves the columns of the B block as they are: the caller renames the columns
     of the RESULT instead (same entries, same values; B keeps its locality)."""
     p = partitions[rank]
@@ -153,7 +166,7 @@ def build_rank_operands(A: HostCsr, B: HostCsr, rank: int, world: int, partition
     inv = np.empty(B.cols, dtype=np.int64)
     inv[B_shuffle] = np.arange(B.cols, dtype=np.int64)
     if relabel_b and not np.array_equal(B_shuffle, np.arange(B.cols)):
-        blk = relabel_cols(blk, inv)
+        blk = relabel_cols(blk, inv, ctx=ctx)
     return RankOperands(A_part, blk, r0, B.rows, B.cols)
 
 
@@ -447,7 +460,7 @@ class DistSpgemm:
             inv[self.B_shuffle] = np.arange(B.cols, dtype=np.int32)
             self.col_new_id = torch.from_numpy(inv).to(self.device)
         self.ops = build_rank_operands(A, B, self.rank, self.world, self.partitions, self.A_shuffle, self.B_shuffle,
-                                       n_sections, relabel_b=not self.late_relabel)
+                                       n_sections, relabel_b=not self.late_relabel, ctx=self.ctx)
         ap = self.ops.A_part
         if stages < 1:
             raise ValueError("stages must be at least 1")

@@ -73,3 +73,51 @@ def test_full_size_erdos_renyi_2_22():
 def test_full_size_rmat_scale_22_u64_offsets():
     """nnz(C) = 8.27e9: row pointer entries beyond 2^32; the sampled tail rows live there."""
     _verify(hostcsr.rmat(22, 4, seed=1), n_random=600, n_heavy=2, expect_u64=True)
+
+
+def test_full_size_erdos_renyi_2_22_shuffle_variant():
+    """The `shuffle` variant (bitmap-filtered exchange + random row and column shuffle, B relabelled
+    on the device before the exchange) at n = 2^22, a world of one rank: the rank's rows of C are the
+    oracle's rows of A * A, in shuffled row order and shuffled column ids, on a sample of rows."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from spgemm_amd import dist as sd
+    A = hostcsr.erdos_renyi(1 << 22, 16, seed=42)
+    started = not dist.is_initialized()
+    if started:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        op = sd.DistSpgemm(A, None, impl="shuffle", n_sections=512, seed=7, device_index=0)
+        try:
+            assert not op.late_relabel                      # a B without column locality is relabelled up front
+            C = op.gemm()
+            rows, cols, nnz = C.info()
+            assert (rows, cols) == (A.rows, A.cols) and nnz > 10 ** 9
+            assert C.check() == (0, 0)                      # sorted rows, columns in range, no stored zero
+            inv = np.empty(A.cols, dtype=np.int64)
+            inv[op.B_shuffle] = np.arange(A.cols, dtype=np.int64)
+            rng = np.random.default_rng(3)
+            sample = np.sort(rng.choice(A.rows, size=600, replace=False))
+            full = orc.OCsr(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+            E = orc.spgemm(full.select_rows(op.A_shuffle[sample]), full)
+            e_ptr = E.row_ptr.astype(np.int64)
+            for i, r in enumerate(sample):
+                rp, ci, v = C.rows_to_host(int(r), 1)
+                lo, hi = e_ptr[i], e_ptr[i + 1]
+                want_c = inv[E.col_idx[lo:hi].astype(np.int64)]
+                order = np.argsort(want_c, kind="stable")
+                assert int(rp[1]) == hi - lo, f"row {r}: {int(rp[1])} entries, oracle {hi - lo}"
+                assert np.array_equal(ci.astype(np.int64), want_c[order]), f"row {r}: columns differ"
+                assert np.array_equal(v.view(np.uint64), E.val[lo:hi][order].view(np.uint64)), f"row {r}: values differ"
+        finally:
+            op.close()
+    finally:
+        if started:
+            dist.destroy_process_group()
