@@ -30,8 +30,11 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
                                                    const uint32_t *__restrict__ b_col,
                                                    RowInfo info) {
   constexpr int G = 8;
-  uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  uint32_t lg = threadIdx.x & (G - 1);
+  const uint32_t lg = threadIdx.x & (G - 1);
+  // (a grid of a few thousand workgroups strides over the rows: a B of which only a few row sections
+  // are present is mostly empty rows, and a workgroup per 32 of them would cost more than the rows do)
+  for (uint64_t row0 = (uint64_t)blockIdx.x * (256 / G); row0 < rows; row0 += (uint64_t)gridDim.x * (256 / G)) {
+  const uint64_t row = row0 + threadIdx.x / G;
   uint32_t mn = 0xFFFFFFFFu, mx = 0, unsorted = 0, differs = 0;
   uint64_t b0 = 0, b1 = 0, bp = 0;
   if (row < rows) {
@@ -58,20 +61,34 @@ __global__ void __launch_bounds__(256) k_b_rowinfo(uint64_t rows, const uint64_t
     if (unsorted) atomicAdd(&info.p[2 * rows].x, 1u);
     if (cmp && !differs && !unsorted && len <= 0xFFFFFFFFull) atomicOr(&info.same[row >> 5], 1u << (row & 31u));
   }
+  }
 }
 
-// longest run of rows with one column list: a row that starts one (its own bit clear, the next row's
-// set) counts the set bits that follow it, up to `cap` rows in all
+// longest run of rows with one column list = 1 + the longest streak of set bits in `same` (a run is a
+// row with its bit clear and the rows with set bits that follow it), capped at `cap`.  One thread per
+// 32-bit word: the longest streak inside the word, and the streak that leaves the word at its top,
+// followed into the next words.  Bits beyond the last row are clear.
 __global__ void __launch_bounds__(256) k_b_maxrun(uint64_t rows, RowInfo info, uint32_t cap) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t run = 0;
-  if (r + 1 < rows) {
-    auto bit = [&](uint64_t k) { return (info.same[k >> 5] >> (k & 31u)) & 1u; };
-    if (!bit(r) && bit(r + 1)) {
-      run = 2;
-      while (run < cap && r + run < rows && bit(r + run)) ++run;
+  const uint64_t words = (rows + 31u) >> 5;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t best = 0;
+  if (t < words) {
+    const uint32_t w = info.same[t];
+    for (uint32_t x = w; x; x &= x << 1) ++best; // rounds until no set bit has a set bit below it
+    uint32_t top = (uint32_t)__clz((int)~w); // set bits at the top of the word (32 when all are set)
+    if (w == 0xFFFFFFFFu) top = 32u;
+    if (top) {
+      uint32_t streak = top;
+      for (uint64_t k = t + 1; k < words && streak < cap; ++k) {
+        const uint32_t n = info.same[k];
+        const uint32_t low = n == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~n); // set bits at the bottom
+        streak += low;
+        if (low < 32u) break;
+      }
+      best = max(best, streak);
     }
   }
+  uint32_t run = best ? min(cap, best + 1u) : 0u;
   run = group_max<64>(run);
   if ((threadIdx.x & 63u) == 0 && run > 1 && run > __hip_atomic_load(&info.p[2 * rows].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&info.p[2 * rows].y, run);

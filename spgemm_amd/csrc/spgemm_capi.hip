@@ -341,10 +341,10 @@ static int ensure_rowinfo(spgemm_ctx *ctx, const spgemm_mat *B) {
   // counters (unsorted rows, longest run of rows with one column list) and the `same` bits start at zero
   HIP_TRY(hipMemsetAsync(mb->d_rowinfo + 2 * B->rows, 0, sizeof(uint4) + rowinfo_same_words(B) * 4, ctx->stream));
   if (B->rows) {
-    uint32_t blocks = div_up_u64(B->rows * 8, 256);
+    uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(B->rows * 8, 256), 8192);
     hipLaunchKernelGGL(k_b_rowinfo, dim3(blocks), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                        rowinfo_of(B));
-    hipLaunchKernelGGL(k_b_maxrun, dim3(div_up_u64(B->rows, 256)), dim3(256), 0, ctx->stream, B->rows, rowinfo_of(B), 255u);
+    hipLaunchKernelGGL(k_b_maxrun, dim3(div_up_u64(div_up_u64(B->rows, 32), 256)), dim3(256), 0, ctx->stream, B->rows, rowinfo_of(B), 255u);
     HIP_TRY(hipGetLastError());
   }
   return SPGEMM_OK;
