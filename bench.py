@@ -114,6 +114,8 @@ def kernel_name(launch):
     """Kernel behind a numeric launch record (spgemm_get_launches)."""
     if launch["path"] == "window_groups":
         return "k_num_window_grp"
+    if launch["path"] == "window_group_runs":
+        return "k_num_grp_run"
     if launch["path"] == "big_rows":
         return "k_num_slice"
     if launch["path"] == "hash" and launch["lanes"] == 1:

@@ -228,7 +228,9 @@ int spgemm_get_stats(const spgemm_ctx *ctx, spgemm_stats *out);
 typedef struct spgemm_launch_info {
   uint32_t phase;  /* 0 symbolic, 1 numeric */
   uint32_t path;   /* 0 window (LDS bitmap), 1 hash (LDS table), 2 global scratch, 3 window for row groups,
-                      4 big rows (symbolic: bitmap windows per workgroup; numeric: output slices) */
+                      4 big rows (symbolic: bitmap windows per workgroup; numeric: output slices),
+                      5 window for row groups where B has runs of rows with one column list (a run is
+                        ranked once and summed in registers) */
   uint32_t lanes;  /* 64: one A entry per wavefront step; 0: flat walk (products laid end to end);
                       256 / 1024: threads of the workgroup that shares one row */
   uint32_t rows;   /* rows handled by the launch */

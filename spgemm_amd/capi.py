@@ -67,7 +67,7 @@ class LaunchInfo(ctypes.Structure):
     def as_dict(self) -> dict:
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["phase"] = ("symbolic", "numeric")[d["phase"]]
-        d["path"] = ("window", "hash", "global", "window_groups", "big_rows")[d["path"]]
+        d["path"] = ("window", "hash", "global", "window_groups", "big_rows", "window_group_runs")[d["path"]]
         return d
 
 

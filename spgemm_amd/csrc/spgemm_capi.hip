@@ -1073,7 +1073,7 @@ static int prof_collect(spgemm_ctx *ctx, const spgemm_mat *A, const uint32_t *r_
     HIP_TRY(hipMemsetAsync(d, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_bin_sums, dim3(std::min<uint32_t>(div_up_u64(r.info.rows, 256), 1024)), dim3(256), 0,
                        ctx->stream, r.rows_bin, r.info.rows, A->d_ptr, ctx->r_nprod_prof, r_nnz, ctx->plan_gcnt,
-                       (uint32_t)((r.info.phase == 0 && r.info.path == 0) || r.info.path == 3), d);
+                       (uint32_t)((r.info.phase == 0 && r.info.path == 0) || r.info.path == 3 || r.info.path == 5), d);
     HIP_TRY(hipGetLastError());
     unsigned long long h[3];
     HIP_TRY(hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -1492,7 +1492,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       size_t region = use_runs ? grp_run_region(compact, words, cap, gmax_lds, tier != 0) : grp_region(compact, words, cap, gmax_lds, alen);
       if (region > lds_max) return fail(SPGEMM_ERR_UNSUPPORTED, "LDS region of %zu bytes does not fit", region);
       uint32_t wpb = pick_wpb(region);
-      TRY(prof_begin(ctx, 1, 3, 64, cnt, words, cap, region * wpb, rows_bin));
+      TRY(prof_begin(ctx, 1, use_runs ? 5 : 3, 64, cnt, words, cap, region * wpb, rows_bin));
       if (use_runs) {
         using run_kernel_t = void (*)(const uint32_t *, uint32_t, Csr, Csr, const uint32_t *, RowMeta, NumOut, uint32_t, uint32_t, uint32_t, uint32_t);
 #define SG_RUN_ROW(W, C, G, T) {k_num_grp_run<W, C, 3, G, T>, k_num_grp_run<W, C, 5, G, T>, k_num_grp_run<W, C, 8, G, T>}

@@ -5,7 +5,7 @@ for w in shell diel er rmat; do
 import json
 d=json.load(open('gpurun_out/bench_$w.json'))
 wm=d['whole_multiply']
-print('$w', round(d['ms_per_step'],2),'ms', round(d['value'],1),'GF/s alg_frac', round(wm['frac_of_hbm_peak'],3), 'comp_frac', round(wm['compulsory_frac_of_hbm_peak'],3), 'copy', round(wm['measured_copy_GBs']), {k:round(v,2) for k,v in wm['phase_ms'].items()})
+print('$w', round(d['ms_per_step'],2),'ms', round(d['value'],1),'GF/s model_no_reuse_frac', round(wm['frac_model_no_reuse'],3), 'comp_frac', round(wm['compulsory_frac_of_hbm_peak'],3), 'copy', round(wm['measured_copy_GBs']), {k:round(v,2) for k,v in wm['phase_ms'].items()})
 print('   dom', d['roofline']['kernel'], round(d['roofline']['kernel_ms'],2), round(d['roofline']['frac'],3))
 PY
 done
