@@ -1,4 +1,4 @@
-// Runs the adapter documented in INTEGRATION.md (extracted into adapter_extracted.hpp by
+// Runs the adapter that the repository's integration guide documents (extracted into adapter_extracted.hpp by
 // tools/extract_adapter.py) on the GPU: a rank's rows of A against two column blocks of B that
 // arrive as filtered blocked blobs, two runs with different section bitmaps; the entries it emits
 // must be the bits of the plain triple loop of the reference's mult_step

@@ -1,5 +1,5 @@
-// Stand-ins for the parts of the reference's headers that the device-resident adapter documented in
-// INTEGRATION.md touches, with the reference's names, members and blob layouts
+// Stand-ins for the parts of the reference's headers that the device-resident adapter of the
+// repository's integration guide touches, with the reference's names, members and blob layouts
 // (include/matrix.hpp:9-31, 63-68; include/matrix_impl.hpp:228-363; src/matrix.cpp:66-68;
 // include/partition.hpp:10-17; include/mults.hpp:17-33).  They exist so that the documented adapter
 // is compiled, and run, by the tests; nothing here is part of the product.

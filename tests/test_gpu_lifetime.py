@@ -49,8 +49,8 @@ def test_destroy_releases_the_matrices_left_on_the_context():
         free_now = torch.cuda.mem_get_info(0)[0]
         if i == 1:
             free0 = free_now
-        if i > 1:   # nothing accumulates from one context to the next (a leak would be > 2 GB per round)
-            assert free_now > free0 - (256 << 20), f"round {i}: {free0 - free_now} bytes fewer free than after round 1"
+        if i > 1:   # nothing accumulates from one context to the next (a leak would be > 2 GB per context)
+            assert free_now > free0 - (256 << 20), f"context {i}: {free0 - free_now} bytes fewer free than after context 1"
 
 
 def test_noalloc_assemble_from_two_contexts_of_one_gpu():

@@ -1,4 +1,4 @@
-"""The adapter INTEGRATION.md shows a maintainer of the reference (a Drop* operator whose B blocks
+"""The adapter that the integration guide shows a maintainer of the reference (a Drop* operator whose B blocks
 stay on the GPU) is compiled from the document's own text against stand-ins for the reference's
 types (tests/integration/ref_stubs.hpp), and run on the GPU against the reference's triple loop."""
 import os
@@ -31,7 +31,7 @@ def test_prebuilt_harness_holds_the_documented_text():
     path = os.path.join(ROOT, "tests", "integration", "adapter_extracted.hpp")
     if not os.path.exists(path):
         pytest.skip("not built yet: python -c 'import __graft_entry__ as g; g.build()'")
-    assert open(path).read() == extract_adapter.adapter_text(), "INTEGRATION.md changed: rebuild (build())"
+    assert open(path).read() == extract_adapter.adapter_text(), "the documented adapter changed: rebuild (build())"
 
 
 @pytest.mark.gpu
