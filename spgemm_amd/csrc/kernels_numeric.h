@@ -290,6 +290,15 @@ constexpr int GRP_RUN_SLOTS = SG_GRP_SLOTS;
 // read per row of the group and B row) instead of being handed from a lane to the scalar unit (two
 // lane reads): fewer vector instructions, more LDS traffic and 8 * GMAX * 64 (128) bytes of LDS more.
 constexpr bool GRP_RUN_ALDS = SG_GRP_ALDS != 0;
+// SG_GRP_ASCALAR: 1: the A values come straight from memory through the scalar unit (the address is
+// wave-uniform) instead of two lane reads of the vector unit per value; 0: never; default: for the
+// wide groups (rows of 65 to 128 entries; measured: the numeric pass of the 3-D grid rows 6.5 -> 6.1 ms,
+// of the shell rows 1.14 -> 1.18 ms, so the narrow groups keep the lane reads).  Issuing the loads of
+// the next B row behind the first use of this one's, so that they land during its additions, lost
+// on both (scalar loads return in any order: every wait is for all that are out).
+#ifndef SG_GRP_ASCALAR
+#define SG_GRP_ASCALAR 2
+#endif
 __host__ __device__ inline size_t grp_run_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, bool wide) {
   return grp_region(compact, words, cap, gmax, 0) + (GRP_RUN_ALDS ? (size_t)gmax * (wide ? 128u : 64u) * 8u : 0u);
 }
@@ -452,8 +461,12 @@ __global__ void __launch_bounds__(256)
     load_tc(g1, tc);
     GR_STAMP(2) // bitmap and prefix counts built, columns of C stored
     // value of A entry t of the group's row j (t wave-uniform)
+    constexpr bool GRP_RUN_ASCALAR = SG_GRP_ASCALAR == 1 || (SG_GRP_ASCALAR == 2 && WIDE);
+    const auto a_val_s = scalar_view(A.val);
+    const uint64_t a_base_s = a0; // (wave-uniform: it came through v_readlane)
     auto a_of = [&](uint32_t j, uint32_t t) {
-      if constexpr (GRP_RUN_ALDS) return avals[j * ALEN + t];
+      if constexpr (GRP_RUN_ASCALAR) return a_val_s[a_base_s + (uint64_t)j * len_a + (uint32_t)__builtin_amdgcn_readfirstlane((int)t)];
+      else if constexpr (GRP_RUN_ALDS) return avals[j * ALEN + t];
       else if constexpr (WIDE) return t < 64u ? readlane_f64(av_lo[j], t) : readlane_f64(av_hi[j], t - 64u);
       else return readlane_f64(av_lo[j], t);
     };
