@@ -6,18 +6,17 @@
 namespace sg {
 
 // ---- symbolic, window path: one wavefront per row ------------------------------------------------
-// LDS per wavefront: a bitmap of `words` 32-bit words covering columns [cmin & ~31, cmax] and, per
-// word, the number of set bits before it as 16 bits (6 bytes per word: the LDS per wavefront sets
+// LDS per wavefront: a bitmap of `words` 32-bit words covering columns [cmin & ~31, cmax] and a list
+// of the words that hold a column, 16 bits each (6 bytes per word: the LDS per wavefront sets
 // how many of them a CU holds, and a hull of 65,536 columns went from 9 to 13 wavefronts per CU).
 //
 // Every product ORs its bit into the bitmap (lanes of one instruction that share a word are
 // serialised by the LDS; combining them first in registers was measured and cost more than it
-// saved).  The sorted column list is then written coalesced: output position p finds the word
-// that holds the p-th set bit by a binary search over the per-word prefix counts.
+// saved).  The sorted column list is then written word by word of the words that hold a column.
 // FLAT: flat walk (short B rows) instead of the scalar-unit walk; adds FLAT_BYTES of LDS per wavefront.
 // same_bits (scalar walk; may be null): RowInfo::same of B - consecutive A entries that select consecutive rows
 // of B with one column list are walked once.
-// LDS per wavefront: bits u32[words] | prefix u16[words] (rounded up to 16 bytes) | flat-walk scratch
+// LDS per wavefront: bits u32[words] | list of non-empty words u16[words] (rounded up to 16 bytes) | flat-walk scratch
 __host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
   return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
 }
@@ -33,7 +32,7 @@ __global__ void __launch_bounds__(256)
   if (idx >= nrows) return;
   const size_t region = sym_window_region(words, FLAT);
   uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);             // words x 32 columns
-  uint16_t *pre = reinterpret_cast<uint16_t *>(smem + w * region + (size_t)words * 4u); // set bits before each word
+  uint16_t *pre = reinterpret_cast<uint16_t *>(smem + w * region + (size_t)words * 4u); // the words that hold a column
   const uint32_t row = rows[idx];
   const uint32_t base = m.cmin[row] & ~31u;
   const uint32_t nw = ((m.cmax[row] - base) >> 5) + 1u;
@@ -62,30 +61,37 @@ __global__ void __launch_bounds__(256)
     }
   }
   lds_fence();
-  // per-word prefix of the set-bit counts (16 bits: the hull of the window path is at most 65,536
-  // columns wide, so fewer than 65,536 bits lie before any word)
-  uint32_t carry = 0;
+  // The words that hold a column (a hull of tens of thousands of columns holds a few hundred) are
+  // listed first: a round of 64 words costs one read and a ballot, no scan and nothing that the next
+  // round waits for.  The listed words are then counted, scanned and written out 64 at a time, every
+  // lane the columns of its own word: neighbouring lanes write neighbouring entries.
+  uint16_t *nzl = pre; // (one entry per word at most)
+  uint32_t nz = 0;
   for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
-    uint32_t wi = r0 + lane;
-    uint32_t pc = wi < nw ? __popc(bm[wi]) : 0u;
-    uint32_t incl = group_incl_scan<64>(pc);
-    if (wi < nw) pre[wi] = (uint16_t)(carry + incl - pc);
-    carry += group_last<64>(incl);
+    const uint32_t wi = r0 + lane;
+    const uint32_t word = wi < nw ? bm[wi] : 0u;
+    const uint64_t mask = __ballot(word != 0u);
+    if (word) nzl[nz + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)wi;
+    nz += (uint32_t)__popcll(mask);
   }
   lds_fence();
-  // output position p -> word holding the p-th set bit (binary search on the prefixes) -> column.
-  // Empty words repeat the prefix of the word after them; the search takes the last word whose
-  // prefix is <= p, which is the one that holds the bit.
-  const uint32_t n = carry;
   uint32_t *out = m.temp_cols + m.t_off[row];
-  for (uint32_t p = lane; p < n; p += 64) {
-    uint32_t lo = 0, hi = nw - 1u;
-    while (lo < hi) {
-      uint32_t mid = (lo + hi + 1u) >> 1;
-      if ((uint32_t)pre[mid] <= p) lo = mid; else hi = mid - 1u;
+  uint32_t carry = 0;
+  for (uint32_t s0 = 0; s0 < nz; s0 += 64) {
+    const uint32_t si = s0 + lane;
+    const uint32_t wi = si < nz ? (uint32_t)nzl[si] : 0u;
+    uint32_t word = si < nz ? bm[wi] : 0u;
+    const uint32_t pc = __popc(word);
+    const uint32_t incl = group_incl_scan<64>(pc);
+    uint32_t at = carry + incl - pc;
+    carry += group_last<64>(incl);
+    const uint32_t cbase = base + (wi << 5);
+    while (word) {
+      out[at++] = cbase + (uint32_t)__ffs(word) - 1u;
+      word &= word - 1u;
     }
-    out[p] = base + (lo << 5) + select_bit(bm[lo], p - (uint32_t)pre[lo]);
   }
+  const uint32_t n = carry;
   // the group's rows share the pattern: same nnz; they are accumulated together when the group
   // kernel has a tier for them, else one by one (each reading the leader's column list)
   const uint32_t cnt = m.gcnt[row];
