@@ -117,6 +117,9 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   once per run: the symbolic one skips the repeats, the
  *                                                   row-group numeric one ranks a column once and sums the
  *                                                   run's products in registers, in the CPU's order; 0: row by row
+ *   sym_rpw, grp_rpw                                1..64 (default 8): rows / row groups a wavefront of those two
+ *                                                   kernels takes one after the other, the next one's
+ *                                                   description in flight (1: one per wavefront)
  *   short_packed                                    1: the numeric one reads the rows of B as 16-byte
  *                                                   {column, value} records padded to 128-byte lines
  *                                                   (built once per B handle, at most 7 records of

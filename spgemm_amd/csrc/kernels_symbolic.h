@@ -20,6 +20,51 @@ namespace sg {
 __host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
   return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
 }
+// The sorted column list of a row from its bitmap; returns the number of columns.
+// The words that hold a column (a hull of tens of thousands of columns holds a few hundred) are
+// listed first: a round of 64 words costs one read and a ballot, no scan and nothing that the next
+// round waits for.  The listed words are then counted, scanned and written out 64 at a time, every
+// lane the columns of its own word: neighbouring lanes write neighbouring entries.
+__device__ __forceinline__ uint32_t sym_window_emit(const uint32_t *bm, uint16_t *nzl /* one entry per word at most */, uint32_t nw,
+                                                    uint32_t base, uint32_t *__restrict__ out, uint32_t lane) {
+  uint32_t nz = 0;
+  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
+    const uint32_t wi = r0 + lane;
+    const uint32_t word = wi < nw ? bm[wi] : 0u;
+    const uint64_t mask = __ballot(word != 0u);
+    if (word) nzl[nz + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)wi;
+    nz += (uint32_t)__popcll(mask);
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t s0 = 0; s0 < nz; s0 += 64) {
+    const uint32_t si = s0 + lane;
+    const uint32_t wi = si < nz ? (uint32_t)nzl[si] : 0u;
+    uint32_t word = si < nz ? bm[wi] : 0u;
+    const uint32_t pc = __popc(word);
+    const uint32_t incl = group_incl_scan<64>(pc);
+    uint32_t at = carry + incl - pc;
+    carry += group_last<64>(incl);
+    const uint32_t cbase = base + (wi << 5);
+    while (word) {
+      out[at++] = cbase + (uint32_t)__ffs(word) - 1u;
+      word &= word - 1u;
+    }
+  }
+  return carry;
+}
+// The group's rows share the pattern: same nnz; they are accumulated together when the group kernel
+// has a tier for them, else one by one (each reading the leader's column list).
+__device__ __forceinline__ void sym_window_finish(const Csr &A, const RowMeta &m, uint32_t row, uint32_t n, uint32_t lane) {
+  const uint32_t cnt = m.gcnt[row];
+  if (lane < cnt) {
+    m.nnz[row + lane] = n;
+    const uint32_t len_a = (uint32_t)min(A.ptr[row + 1] - A.ptr[row], (uint64_t)0xFFFFFFFFu);
+    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, len_a);
+    const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
+    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
+  }
+}
 constexpr int SYM_RUN_SLOTS = 6;
 template <bool FLAT, bool TAIL = false> // TAIL: see RowWalk (scalar walk only)
 __global__ void __launch_bounds__(256)
@@ -61,46 +106,72 @@ __global__ void __launch_bounds__(256)
     }
   }
   lds_fence();
-  // The words that hold a column (a hull of tens of thousands of columns holds a few hundred) are
-  // listed first: a round of 64 words costs one read and a ballot, no scan and nothing that the next
-  // round waits for.  The listed words are then counted, scanned and written out 64 at a time, every
-  // lane the columns of its own word: neighbouring lanes write neighbouring entries.
-  uint16_t *nzl = pre; // (one entry per word at most)
-  uint32_t nz = 0;
-  for (uint32_t r0 = 0; r0 < nw; r0 += 64) {
-    const uint32_t wi = r0 + lane;
-    const uint32_t word = wi < nw ? bm[wi] : 0u;
-    const uint64_t mask = __ballot(word != 0u);
-    if (word) nzl[nz + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)wi;
-    nz += (uint32_t)__popcll(mask);
+  const uint32_t n = sym_window_emit(bm, pre, nw, base, m.temp_cols + m.t_off[row], lane);
+  sym_window_finish(A, m, row, n, lane);
+}
+
+// The same for a B with runs of rows with one column list (same_bits), scalar walk: a wavefront takes
+// rpw (<= 64) consecutive rows of its bin, one after the other.  What a row needs before its first
+// column sits behind a chain of dependent loads (row id -> row state -> column indices of the A row ->
+// bounds of the B rows -> B entries); the chain is taken off the critical path as in k_num_grp_run:
+// lane i holds row i's state, the description of the next row is loaded while this one is walked.
+__global__ void __launch_bounds__(256)
+    k_sym_window_runs(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t words,
+                      const uint32_t *__restrict__ same_bits, uint32_t wpb, uint32_t rpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
+  if (w >= wpb || first64 >= nrows) return;
+  const uint32_t first = (uint32_t)first64, ng = min(rpw, nrows - first);
+  const size_t region = sym_window_region(words, false);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);
+  uint16_t *pre = reinterpret_cast<uint16_t *>(smem + w * region + (size_t)words * 4u);
+  const uint32_t st_row = rows[first + min(lane, ng - 1u)];
+  const uint32_t st_cmin = m.cmin[st_row], st_cmax = m.cmax[st_row];
+  const uint64_t st_toff = m.t_off[st_row], st_a0 = A.ptr[st_row];
+  const uint64_t st_len64 = A.ptr[(uint64_t)st_row + 1u] - st_a0;
+  const uint32_t st_len = (uint32_t)min(st_len64, (uint64_t)128u); // what the registers describe
+  const uint32_t st_long = st_len64 > 128u ? 1u : 0u;              // such a row is walked through scalar loads
+  auto rl32 = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+  RowRuns<true> cur, nxt;
+  cur.issue_a(A, readlane64(st_a0, 0), max(rl32(st_len, 0), 1u), lane);
+  {
+    const uint32_t g1 = min(1u, ng - 1u);
+    nxt.issue_a(A, readlane64(st_a0, g1), max(rl32(st_len, g1), 1u), lane);
   }
-  lds_fence();
-  uint32_t *out = m.temp_cols + m.t_off[row];
-  uint32_t carry = 0;
-  for (uint32_t s0 = 0; s0 < nz; s0 += 64) {
-    const uint32_t si = s0 + lane;
-    const uint32_t wi = si < nz ? (uint32_t)nzl[si] : 0u;
-    uint32_t word = si < nz ? bm[wi] : 0u;
-    const uint32_t pc = __popc(word);
-    const uint32_t incl = group_incl_scan<64>(pc);
-    uint32_t at = carry + incl - pc;
-    carry += group_last<64>(incl);
-    const uint32_t cbase = base + (wi << 5);
-    while (word) {
-      out[at++] = cbase + (uint32_t)__ffs(word) - 1u;
-      word &= word - 1u;
+  cur.issue_b(B, same_bits);
+  for (uint32_t g = 0; g < ng; ++g) {
+    const uint32_t g2 = min(g + 2u, ng - 1u);
+    const uint32_t row = rl32(st_row, g);
+    const uint32_t base = rl32(st_cmin, g) & ~31u;
+    const uint32_t nw = ((rl32(st_cmax, g) - base) >> 5) + 1u;
+    const bool is_long = rl32(st_long, g) != 0u;
+    for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
+    cur.len_a = rl32(st_len, g); // (a row without entries cannot be here; the loads above assumed one entry at least)
+    cur.finish(lane);
+    nxt.issue_b(B, same_bits);
+    RowRuns<true> aft;
+    aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);
+    lds_fence();
+    auto mark = [&](uint32_t col, double, double, uint32_t) {
+      if (col == EMPTY_KEY) return;
+      const uint32_t c = col - base;
+      atomicOr(&bm[c >> 5], 1u << (c & 31u));
+    };
+    if (!is_long) { // wave-uniform
+      RunPipe<255, false, SYM_RUN_SLOTS, true> pipe;
+      pipe.begin(B, cur, lane);
+      pipe.run(B, cur, lane, [&](const RunInfo &, const RunVec<1> &v) { mark(v.ok ? v.col : EMPTY_KEY, 0.0, 0.0, 0u); });
+    } else {
+      wave_row_walk<false, false, false>(A, B, row, lane, mark, same_bits); // (an entry that repeats a column list is skipped)
     }
-  }
-  const uint32_t n = carry;
-  // the group's rows share the pattern: same nnz; they are accumulated together when the group
-  // kernel has a tier for them, else one by one (each reading the leader's column list)
-  const uint32_t cnt = m.gcnt[row];
-  if (lane < cnt) {
-    m.nnz[row + lane] = n;
-    const uint32_t len_a = (uint32_t)min(A.ptr[row + 1] - A.ptr[row], (uint64_t)0xFFFFFFFFu);
-    const uint32_t gkey = num_key_of(m.sym_key[row], n, m.hash_num_max, cnt, len_a);
-    const bool grouped = gkey >= (uint32_t)NUM_GRP0 && gkey != KEY_NONE;
-    m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
+    lds_fence();
+    const uint32_t n = sym_window_emit(bm, pre, nw, base, m.temp_cols + readlane64(st_toff, g), lane);
+    sym_window_finish(A, m, row, n, lane);
+    lds_fence(); // the next row clears the bitmap
+    cur = nxt;
+    nxt = aft;
   }
 }
 

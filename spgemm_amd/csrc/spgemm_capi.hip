@@ -126,6 +126,7 @@ struct spgemm_ctx {
   uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
   uint32_t grp_rpw = 8;          // most groups one wavefront of the run kernel takes one after the other (<= 64)
+  uint32_t sym_rpw = 8;          // the same for the symbolic window kernel of a B with runs (1: one row per wavefront, the plain kernel)
   int cu_count = 256;
   void *h_pinned = nullptr; // small host staging buffer
   void *d_pinned = nullptr; // the same buffer as the device addresses it (k_report writes results into it)
@@ -479,6 +480,7 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>); raise_lds_limit(k_sym_window<false, true>);
+  raise_lds_limit(k_sym_window_runs);
   raise_lds_limit(k_num_window_grp<0, false>); raise_lds_limit(k_num_window_grp<1, false>); raise_lds_limit(k_num_window_grp<2, false>);
   raise_lds_limit(k_num_window_grp<0, true>); raise_lds_limit(k_num_window_grp<1, true>); raise_lds_limit(k_num_window_grp<2, true>);
   raise_lds_limit(k_num_window_grp<0, false, true>); raise_lds_limit(k_num_window_grp<1, false, true>); raise_lds_limit(k_num_window_grp<2, false, true>);
@@ -788,6 +790,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "big_sym_bounds") {
     if (value > 1) return fail(SPGEMM_ERR_INVALID, "big_sym_bounds must be 0 or 1");
     ctx->big_sym_bounds = (uint32_t)value;
+  } else if (n == "sym_rpw") {
+    if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "sym_rpw must be 1..64");
+    ctx->sym_rpw = (uint32_t)value;
   } else if (n == "grp_rpw") {
     if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "grp_rpw must be 1..64");
     ctx->grp_rpw = (uint32_t)value;
@@ -1274,6 +1279,12 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       auto sym_kern = k_sym_window<false, false>;
       if (flat) sym_kern = k_sym_window<true, false>;
       else if (walk_tail(ctx, B)) sym_kern = k_sym_window<false, true>;
+      if (!flat && same_bits && ctx->sym_rpw > 1) {
+        // B has runs of rows with one column list: the kernel whose wavefronts take several rows, the next one's description in flight
+        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->sym_rpw, cnt / ((uint64_t)ctx->cu_count * 32 * 16)));
+        hipLaunchKernelGGL(k_sym_window_runs, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream,
+                           rows_bin, cnt, cA, cB, rm, words, same_bits, wpb, rpw);
+      } else
       hipLaunchKernelGGL(sym_kern, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
                          region * wpb, ctx->stream, rows_bin, cnt, cA, cB, rm, words, same_bits);
     } else if (key < SYM_GLOBAL0) {

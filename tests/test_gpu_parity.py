@@ -277,6 +277,14 @@ def test_row_groups_identical_patterns(ctx, dofs):
         check(ctx, A, A)
     finally:
         ctx.set_option("row_groups", 1)
+    # one row / one group per wavefront instead of several with the next one's description in flight
+    ctx.set_option("sym_rpw", 1)
+    ctx.set_option("grp_rpw", 1)
+    try:
+        check(ctx, A, A)
+    finally:
+        ctx.set_option("sym_rpw", 8)
+        ctx.set_option("grp_rpw", 8)
 
 
 def test_row_groups_with_cancellation_and_order(ctx):
