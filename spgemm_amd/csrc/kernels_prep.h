@@ -204,18 +204,35 @@ __global__ void __launch_bounds__(256)
       cmp = (a0 - p0) == (a1 - a0) && a1 > a0;
     }
     differs = cmp ? 0u : 1u;
-    for (uint64_t ka = a0 + lg; ka < a1; ka += G) {
-      uint32_t kcol = a_col[ka];
-      if (cmp && a_col[p0 + (ka - a0)] != kcol) differs = 1;
-      uint4 bi = b_info.lo(kcol);
-      if (one_pass) {
-        keep_lo = bi;
-        keep_hi = b_info.hi(kcol); // (the other half of the record: the same line)
+    // U entries per lane at a time: their column indices are loaded together, then their records
+    // (one entry after the other, a row of 35 entries at 8 lanes waited for ten dependent loads)
+    constexpr int U = 4;
+    for (uint64_t kb = a0 + lg; kb < a1; kb += (uint64_t)G * U) {
+      uint32_t kcol[U], pcol[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ka = kb + (uint64_t)u * G;
+        kcol[u] = ka < a1 ? a_col[ka] : 0u;
+        pcol[u] = (cmp && ka < a1) ? a_col[p0 + (ka - a0)] : kcol[u];
       }
-      if (bi.z) {
-        np += bi.z;
-        mn = min(mn, bi.x);
-        mx = max(mx, bi.y);
+      uint4 bi[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t ka = kb + (uint64_t)u * G;
+        bi[u] = ka < a1 ? b_info.lo(kcol[u]) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (one_pass) { // (a single entry per lane: u = 0)
+        keep_lo = bi[0];
+        keep_hi = b_info.hi(kcol[0]); // (the other half of the record: the same line)
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (pcol[u] != kcol[u]) differs = 1;
+        if (bi[u].z) {
+          np += bi[u].z;
+          mn = min(mn, bi[u].x);
+          mx = max(mx, bi[u].y);
+        }
       }
     }
   }
