@@ -10,6 +10,7 @@
 #pragma once
 
 #include <algorithm>
+#include <charconv>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -19,9 +20,15 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #define ROUND8(x) (((x) + 7) & ~(size_t)7)
 
@@ -55,13 +62,86 @@ template <typename T> struct Triplets {
 
 namespace utils {
 
-// Matrix Market `coordinate real|integer|pattern general|symmetric` reader.  Symmetric input is
-// expanded; values are parsed with strtod (correctly rounded).
+// Matrix Market `coordinate real|integer|pattern general|symmetric` reader (the reference maps the
+// file and hands it to a multi-threaded parser, include/matrix_impl.hpp:158-226).  The file is mapped,
+// the entry lines are cut into one piece per thread at line ends, every thread parses its piece with
+// std::from_chars (correctly rounded, no locale, no terminating NUL needed) and the pieces are joined in
+// file order, so rows keep the order in which the file lists their entries.  Symmetric input is
+// expanded.  Threads: SPGEMM_IO_THREADS, else OMP_NUM_THREADS, else the hardware's, at most 64.
+namespace detail {
+struct MappedFile {
+  const char *p = nullptr;
+  size_t n = 0;
+  int fd = -1;
+  explicit MappedFile(const std::string &path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("could not open file (reading): " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("could not stat " + path); }
+    n = (size_t)st.st_size;
+    if (n) {
+      void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { ::close(fd); throw std::runtime_error("could not map " + path); }
+      p = static_cast<const char *>(m);
+    }
+  }
+  ~MappedFile() {
+    if (p) munmap(const_cast<char *>(p), n);
+    if (fd >= 0) ::close(fd);
+  }
+  MappedFile(const MappedFile &) = delete;
+  MappedFile &operator=(const MappedFile &) = delete;
+};
+inline unsigned io_threads() {
+  for (const char *name : {"SPGEMM_IO_THREADS", "OMP_NUM_THREADS"})
+    if (const char *e = std::getenv(name)) {
+      const long v = std::strtol(e, nullptr, 10);
+      if (v >= 1) return (unsigned)std::min<long>(v, 64);
+    }
+  return std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+}
+inline const char *skip_blank(const char *p, const char *end) {
+  while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+  return p;
+}
+// the entry lines of [p, end) (whole lines); false on a malformed line
+template <typename T>
+bool parse_entries(const char *p, const char *end, bool pattern, bool symmetric, std::vector<midx_t> &rows,
+                   std::vector<midx_t> &cols, std::vector<T> &vals, size_t *entries) {
+  size_t n = 0;
+  while (p < end) {
+    p = skip_blank(p, end);
+    if (p < end && *p != '\n' && *p != '%') {
+      unsigned long long r = 0, c = 0;
+      auto a = std::from_chars(p, end, r);
+      if (a.ec != std::errc()) return false;
+      p = skip_blank(a.ptr, end);
+      a = std::from_chars(p, end, c);
+      if (a.ec != std::errc() || r == 0 || c == 0) return false;
+      p = a.ptr;
+      double v = 1.0;
+      if (!pattern) {
+        p = skip_blank(p, end);
+        if (p < end && *p == '+') ++p; // (from_chars takes no leading plus sign)
+        auto d = std::from_chars(p, end, v);
+        if (d.ec == std::errc::invalid_argument) return false;
+        p = d.ptr; // (out of range: the nearest representable value was stored, as strtod does)
+      }
+      rows.push_back((midx_t)(r - 1)); cols.push_back((midx_t)(c - 1)); vals.push_back((T)v);
+      if (symmetric && r != c) { rows.push_back((midx_t)(c - 1)); cols.push_back((midx_t)(r - 1)); vals.push_back((T)v); }
+      ++n;
+    }
+    while (p < end && *p != '\n') ++p; // rest of the line (a complex or extra field is ignored)
+    if (p < end) ++p;
+  }
+  *entries = n;
+  return true;
+}
+} // namespace detail
+
 template <typename T> Triplets<T> read_matrix_market(const std::string &path) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f.is_open()) throw std::runtime_error("could not open file (reading): " + path);
-  std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  const char *p = text.c_str(), *end = p + text.size();
+  detail::MappedFile file(path);
+  const char *p = file.p, *end = file.p + file.n;
   auto line_end = [&](const char *q) { while (q < end && *q != '\n') ++q; return q; };
   const char *le = line_end(p);
   std::string header(p, le);
@@ -72,25 +152,60 @@ template <typename T> Triplets<T> read_matrix_market(const std::string &path) {
   const bool pattern = header.find("pattern") != std::string::npos;
   p = le < end ? le + 1 : end;
   while (p < end && (*p == '%' || *p == '\n' || *p == '\r')) p = std::min(end, line_end(p) + 1);
-  char *q = nullptr;
+  // the size line
+  unsigned long long dims[3] = {0, 0, 0};
+  for (auto &d : dims) {
+    p = detail::skip_blank(p, end);
+    auto a = std::from_chars(p, end, d);
+    if (a.ec != std::errc()) throw std::runtime_error("bad size line in " + path);
+    p = a.ptr;
+  }
+  p = std::min(end, line_end(p) + 1);
   Triplets<T> t;
-  t.nrows = (midx_t)strtoull(p, &q, 10); p = q;
-  t.ncols = (midx_t)strtoull(p, &q, 10); p = q;
-  size_t nnz = strtoull(p, &q, 10); p = q;
-  t.rows.reserve(symmetric ? 2 * nnz : nnz);
-  t.cols.reserve(symmetric ? 2 * nnz : nnz);
-  t.vals.reserve(symmetric ? 2 * nnz : nnz);
-  for (size_t i = 0; i < nnz; ++i) {
-    unsigned long long r = strtoull(p, &q, 10);
-    if (q == p) throw std::runtime_error("truncated Matrix Market file " + path);
-    p = q;
-    unsigned long long c = strtoull(p, &q, 10); p = q;
-    double v = 1.0;
-    if (!pattern) { v = strtod(p, &q); p = q; }
-    t.rows.push_back((midx_t)(r - 1)); t.cols.push_back((midx_t)(c - 1)); t.vals.push_back((T)v);
-    if (symmetric && r != c) {
-      t.rows.push_back((midx_t)(c - 1)); t.cols.push_back((midx_t)(r - 1)); t.vals.push_back((T)v);
-    }
+  t.nrows = (midx_t)dims[0];
+  t.ncols = (midx_t)dims[1];
+  const size_t nnz = dims[2];
+  // one piece per thread, cut at line ends (a piece of at least 1 MiB: small files take one thread)
+  const size_t body = (size_t)(end - p);
+  const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(detail::io_threads(), body >> 20));
+  std::vector<const char *> cut(nt + 1, end);
+  cut[0] = p;
+  for (unsigned i = 1; i < nt; ++i) {
+    const char *q = std::max(p + body * i / nt, cut[i - 1]);
+    const char *e = line_end(q);
+    cut[i] = e < end ? e + 1 : end;
+  }
+  struct Piece { std::vector<midx_t> rows, cols; std::vector<T> vals; size_t entries = 0; bool ok = true; };
+  std::vector<Piece> piece(nt);
+  auto work = [&](unsigned i) {
+    Piece &pc = piece[i];
+    const size_t guess = (size_t)((double)nnz * (double)(cut[i + 1] - cut[i]) / (double)std::max<size_t>(body, 1) * 1.05) + 16;
+    pc.rows.reserve(symmetric ? 2 * guess : guess);
+    pc.cols.reserve(symmetric ? 2 * guess : guess);
+    pc.vals.reserve(symmetric ? 2 * guess : guess);
+    pc.ok = detail::parse_entries<T>(cut[i], cut[i + 1], pattern, symmetric, pc.rows, pc.cols, pc.vals, &pc.entries);
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  size_t entries = 0, total = 0;
+  for (auto &pc : piece) {
+    if (!pc.ok) throw std::runtime_error("malformed entry line in Matrix Market file " + path);
+    entries += pc.entries;
+    total += pc.vals.size();
+  }
+  if (entries < nnz) throw std::runtime_error("truncated Matrix Market file " + path);
+  if (entries > nnz) throw std::runtime_error("more entry lines than the size line announces in " + path);
+  t.rows.resize(total); t.cols.resize(total); t.vals.resize(total);
+  size_t at = 0;
+  for (auto &pc : piece) { // (in file order)
+    std::copy(pc.rows.begin(), pc.rows.end(), t.rows.begin() + at);
+    std::copy(pc.cols.begin(), pc.cols.end(), t.cols.begin() + at);
+    std::copy(pc.vals.begin(), pc.vals.end(), t.vals.begin() + at);
+    at += pc.vals.size();
   }
   return t;
 }
@@ -263,6 +378,7 @@ template <typename T = double> class BlockedCSRMatrix {
   size_t n_sections_ = 0;
   std::vector<CSRMatrix<T>> csrs;
   std::vector<size_t> start_rows;
+  std::vector<int> slot_of_section; // per section of the unfiltered matrix: its position in csrs, -1 when filtered away
 
   size_t *hdr() { return reinterpret_cast<size_t *>(blob.data()); }
   const size_t *hdr() const { return reinterpret_cast<const size_t *>(blob.data()); }
@@ -279,6 +395,10 @@ template <typename T = double> class BlockedCSRMatrix {
       non_zeros += csrs.back().non_zeros;
     }
     width = n_sections_ ? csrs[0].width : 0;
+    slot_of_section.assign(full_sections, -1);
+    const size_t sh = full_sections ? height / full_sections : 0;
+    for (size_t i = 0; i < n_sections_ && sh; ++i)
+      slot_of_section[std::min<size_t>(start_rows[i] / sh, full_sections - 1)] = (int)i;
   }
 
 public:
@@ -329,8 +449,8 @@ public:
   SmallVec<T> row(midx_t i) const {
     size_t sh = height / full_sections;
     size_t s = std::min<size_t>(i / sh, full_sections - 1), start = s * sh;
-    for (size_t k = 0; k < n_sections_; ++k)
-      if (start_rows[k] == start) return csrs[k].row((midx_t)(i - start));
+    const int k = slot_of_section.at(s); // (one table look-up, as the reference's map from start row to section)
+    if (k >= 0) return csrs[(size_t)k].row((midx_t)(i - start));
     throw std::out_of_range("BlockedCSRMatrix::row: section is not present");
   }
 
