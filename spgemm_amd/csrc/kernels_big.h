@@ -587,6 +587,43 @@ __device__ __forceinline__ void lower_bound_col_n(const uint32_t *__restrict__ c
   }
 }
 
+// ---- column sample of B: the last column of every block of 32 entries (block j = entries [32 j, 32 j + 32)
+// of B.col, 128 bytes = one cache line; the last block is padded with the largest column) ------------
+// A search for a column inside a row of B first narrows its range to one block over the sample -
+// 1/32 of B.col, 2 MB for 16 M entries, resident in L2 - and finishes inside that block's line.
+// The plain binary search pulled a whole line for every one of its far probes, and the kernel that
+// searches most is bound by the lines it pulls in.
+constexpr uint32_t SAMPLE_LOG2 = 5;
+__global__ void __launch_bounds__(256) k_b_colsample(uint64_t nnz, const uint32_t *__restrict__ b_col, uint32_t *__restrict__ samp) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t nb = (nnz + 31u) >> SAMPLE_LOG2;
+  if (j >= nb) return;
+  const uint64_t last = min(nnz - 1u, (j << SAMPLE_LOG2) + 31u);
+  samp[j] = b_col[last];
+}
+// first position in [lo, hi) of B.col (one row's range, strictly increasing) whose column is >= key
+__device__ __forceinline__ uint64_t lower_bound_sampled(const uint32_t *__restrict__ col, const uint32_t *__restrict__ samp,
+                                                        uint64_t lo, uint64_t hi, uint64_t key) {
+  if (lo >= hi) return lo;
+  // blocks that lie inside the range as a whole: their last columns belong to this row and increase
+  uint64_t j0 = (lo + 31u) >> SAMPLE_LOG2, j1 = hi >> SAMPLE_LOG2;
+  if (j0 < j1) {
+    uint64_t a = j0, b = j1;
+    while (a < b) { // first whole block whose last column is >= key
+      const uint64_t mid = a + ((b - a) >> 1);
+      if ((uint64_t)samp[mid] < key) a = mid + 1; else b = mid;
+    }
+    // every entry of the whole blocks before block a is < key; the head before block j0 only when a > j0
+    if (a > j0) lo = a << SAMPLE_LOG2;
+    if (a < j1) hi = (a << SAMPLE_LOG2) + 32u;
+  }
+  while (lo < hi) { // at most two lines
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if ((uint64_t)col[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // `work`: SLICE_QUEUE_STRIDE * q = items handed out from queue q (zero on entry); queue q holds the
 // items [total * q / queues, total * (q + 1) / queues), total = n_items[0].  Workgroups are dealt to
 // the eight XCDs round robin, so workgroup b starts on queue b % queues and moves on to the next
@@ -602,7 +639,8 @@ constexpr uint32_t SLICE_QUEUE_STRIDE = 16; // counters, in uint64: one 128-byte
 __global__ void __launch_bounds__(64)
     k_num_slice(const SliceItem *__restrict__ items, const uint64_t *__restrict__ n_items, Csr A, Csr B, RowMeta m,
                 NumOut o, unsigned long long *__restrict__ work, unsigned char *__restrict__ list_scratch,
-                uint64_t list_cap, uint64_t nnz_b, const Rec12 *__restrict__ packed, uint32_t queues, uint32_t hw_order) {
+                uint64_t list_cap, uint64_t nnz_b, const Rec12 *__restrict__ packed, uint32_t queues, uint32_t hw_order,
+                const uint32_t *__restrict__ samp) {
   // the entries of B as 12-byte records {column, value} (optional): a short piece of a row of B (a few
   // entries, the common case inside a chunk) then lies in one 128-byte line, or two, instead of one
   // line of columns and one of values, and this kernel is bound by the lines it pulls in
@@ -626,8 +664,10 @@ __global__ void __launch_bounds__(64)
 #endif
     }
   };
+  // (samp: the column sample of B, see k_b_colsample; null: plain binary search, as with the packed records)
   auto lbound = [&](uint64_t lo, uint64_t hi, uint64_t key) {
-    return packed ? lower_bound_col<3>(pcol, lo, hi, key) : lower_bound_col<1>(B.col, lo, hi, key);
+    if (packed) return lower_bound_col<3>(pcol, lo, hi, key);
+    return samp ? lower_bound_sampled(B.col, samp, lo, hi, key) : lower_bound_col<1>(B.col, lo, hi, key);
   };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *scol = reinterpret_cast<uint32_t *>(smem);
@@ -722,7 +762,10 @@ __global__ void __launch_bounds__(64)
           }
         }
         if (packed) lower_bound_col_n<U, 3>(pcol, lo, hi, clo_item);
-        else lower_bound_col_n<U, 1>(B.col, lo, hi, clo_item);
+        else if (samp) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) lo[u] = lower_bound_sampled(B.col, samp, lo[u], hi[u], clo_item); // (probes of the sample: L2 hits)
+        } else lower_bound_col_n<U, 1>(B.col, lo, hi, clo_item);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t nc0 = lo[u] < b1[u] ? bcol(lo[u]) : EMPTY_KEY;

@@ -67,6 +67,8 @@ struct spgemm_mat {
   uint64_t prec_slots = 0;    // record slots in d_prec; the padded column array follows them
   Rec12 *d_packed = nullptr;  // the entries as 12-byte records {column, value}, read by the big-row numeric kernel (option)
   size_t bytes_packed = 0;
+  uint32_t *d_samp = nullptr; // last column of every block of 32 entries (the big-row numeric kernel searches over it)
+  size_t bytes_samp = 0;
   uint32_t *d_wb = nullptr;   // big-row symbolic kernel: first entry of every row in every window of 2^wb_ws columns (k_b_winbounds)
   size_t bytes_wb = 0;
   uint32_t wb_nwin = 0, wb_ws = 0;
@@ -120,6 +122,7 @@ struct spgemm_ctx {
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
   uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
   uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 12-byte {column, value} records
+  uint32_t slice_sampled = 1;    // 1: its searches inside rows of B go over a 1-in-32 sample of B's columns first
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
@@ -382,6 +385,18 @@ static int ensure_prec(spgemm_ctx *ctx, const spgemm_mat *B) {
   mb->prec_slots = slots;
   hipLaunchKernelGGL(k_prec_fill, dim3(div_up_u64(B->rows * 8, 256)), dim3(256), 0, ctx->stream, B->rows, B->d_ptr, B->d_col,
                      B->d_val, rowinfo_of(B), mb->d_prec, reinterpret_cast<uint32_t *>(mb->d_prec + slots));
+  HIP_TRY(hipGetLastError());
+  return SPGEMM_OK;
+}
+
+// The column sample of B (k_b_colsample) for the big-row numeric kernel: built when that kernel first
+// needs it, kept on the handle like the row info (which it is released with).
+static int ensure_colsample(spgemm_ctx *ctx, const spgemm_mat *B) {
+  if (B->d_samp || !B->nnz) return SPGEMM_OK;
+  spgemm_mat *mb = const_cast<spgemm_mat *>(B);
+  const uint64_t nb = (B->nnz + 31) / 32;
+  TRY(pool_alloc(ctx, nb * 4 + 16, (void **)&mb->d_samp, &mb->bytes_samp));
+  hipLaunchKernelGGL(k_b_colsample, dim3((uint32_t)div_up_u64(nb, 256)), dim3(256), 0, ctx->stream, B->nnz, B->d_col, mb->d_samp);
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -811,6 +826,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "slice_sorted") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0 or 1");
     ctx->slice_sorted = (uint32_t)value;
+  } else if (n == "slice_sampled") {
+    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_sampled must be 0 or 1");
+    ctx->slice_sampled = (uint32_t)value;
   } else if (n == "slice_packed") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_packed must be 0 or 1");
     ctx->slice_packed = (uint32_t)value;
@@ -999,6 +1017,9 @@ extern "C" int spgemm_mat_invalidate(spgemm_ctx *ctx, spgemm_mat *m) {
     if (m->d_wb) pool_release(ctx, m->d_wb, m->bytes_wb);
     m->d_wb = nullptr;
     m->bytes_wb = 0;
+    if (m->d_samp) pool_release(ctx, m->d_samp, m->bytes_samp);
+    m->d_samp = nullptr;
+    m->bytes_samp = 0;
     m->d_rowinfo = nullptr;
     m->d_colcdf = nullptr;
     m->d_packed = nullptr;
@@ -1019,6 +1040,7 @@ static void release_mat(spgemm_ctx *ctx, spgemm_mat *m) {
   if (m->d_prow) pool_release(ctx, m->d_prow, m->bytes_prow);
   if (m->d_prec) pool_release(ctx, m->d_prec, m->bytes_prec);
   if (m->d_wb) pool_release(ctx, m->d_wb, m->bytes_wb);
+  if (m->d_samp) pool_release(ctx, m->d_samp, m->bytes_samp);
   if (m->d_rowlen) pool_release(ctx, m->d_rowlen, m->bytes_rowlen);
   if (m->owns) {
     pool_release(ctx, m->d_ptr, m->bytes_ptr);
@@ -1599,6 +1621,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       SliceItem *s_items_sorted = reinterpret_cast<SliceItem *>(reinterpret_cast<char *>(s_key_out) + b_keys);
       void *s_sort_tmp = reinterpret_cast<char *>(s_items_sorted) + b_items;
       if (ctx->slice_packed) TRY(ensure_packed(ctx, B));
+      else if (ctx->slice_sampled) TRY(ensure_colsample(ctx, B));
       TRY(prof_begin(ctx, 1, 4, 64, cnt, SLICE_W, blocks, slice_lds(hw_order), rows_bin));
       hipLaunchKernelGGL(k_slice_count, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
                          pl.r_nnz, s_count, ctx->slice_run_min, ctx->slice_run_div);
@@ -1615,7 +1638,8 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       }
       hipLaunchKernelGGL(k_num_slice, dim3(blocks), dim3(64), slice_lds(hw_order), ctx->stream,
                          sort_n ? s_items_sorted : s_items, s_off + cnt, cA, cB, rm, no,
-                         zero_count + 32, s_lists, list_cap, B->nnz, ctx->slice_packed ? B->d_packed : nullptr, ctx->slice_queues, hw_order);
+                         zero_count + 32, s_lists, list_cap, B->nnz, ctx->slice_packed ? B->d_packed : nullptr, ctx->slice_queues, hw_order,
+                         ctx->slice_sampled && !ctx->slice_packed ? B->d_samp : nullptr);
     } else {
       uint64_t words_total = (B->cols + 31) / 32 + 1;
       uint32_t blocks = std::min<uint32_t>(cnt, ctx->global_blocks_num);
