@@ -302,19 +302,26 @@ def run_single(args):
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A)
-    # the second workload the target names: R-MAT scale 22 (edge factor 4), a bounded number of steps
+    # the other workloads of the benchmark set, a bounded number of steps each: R-MAT scale 22 (the
+    # second workload the target names), the 3-D grid stand-in and Erdos-Renyi 2^22
     if args.workload == "shell" and not args.no_also:
         del A
-        R = hostcsr.rmat(22, 4, seed=1)
+        out["also"] = []
         k = max(1, min(args.steps, 5))
-        ms2, st2, l2, roof2, whole2 = measure_workload(ctx, R, "rmat", k, 1, args.opt)
-        out["also"] = [{
-            "config": {"workload": "R-MAT scale 22, edge factor 4, C=A*A", "rows": R.rows, "nnz_a": R.nnz,
-                       "nprod": st2["nprod"], "nnz_c": st2["nnz_c"], "impl": "baseline", "parallelism": "1 GPU"},
-            "steps": k, "warmup": 1, "ms_per_step": ms2, "value": 2.0 * st2["nprod"] / (ms2 * 1e-3) / 1e9, "unit": "GFLOP/s",
-            "roofline": roof2, "whole_multiply": whole2,
-            "launches": [{kk: l[kk] for kk in ("phase", "path", "lanes", "rows", "ms", "lds_bytes", "nprod", "nnz_c")} for l in l2],
-        }]
+        for key, make, label in (("rmat", lambda: hostcsr.rmat(22, 4, seed=1), "R-MAT scale 22, edge factor 4, C=A*A"),
+                                 ("diel", hostcsr.diel_like, "dielFilterV3real-like synthetic 3-D grid (n=1104192, ~81 nnz/row), C=A*A"),
+                                 ("er", lambda: hostcsr.erdos_renyi(1 << 22, 16, seed=42), "Erdos-Renyi n=4194304, 16 draws/row, C=A*A")):
+            M = make()
+            ms2, st2, l2, roof2, whole2 = measure_workload(ctx, M, key, k, 1, args.opt)
+            out["also"].append({
+                "config": {"workload": label, "rows": M.rows, "nnz_a": M.nnz, "nprod": st2["nprod"], "nnz_c": st2["nnz_c"],
+                           "impl": "baseline", "parallelism": "1 GPU",
+                           "stand_in": "synthetic matrix of the named SuiteSparse matrix's order and row length" if key == "diel" else None},
+                "steps": k, "warmup": 1, "ms_per_step": ms2, "value": 2.0 * st2["nprod"] / (ms2 * 1e-3) / 1e9, "unit": "GFLOP/s",
+                "roofline": roof2, "whole_multiply": whole2,
+                "launches": [{kk: l[kk] for kk in ("phase", "path", "lanes", "rows", "ms", "lds_bytes", "nprod", "nnz_c")} for l in l2],
+            })
+            del M
     ctx.close()
     print(json.dumps(out))
 
@@ -339,7 +346,7 @@ def main():
                          "exchange of the next block with the multiply of the current one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
-                    help="default run (shell) only: leave out the block of the R-MAT scale-22 workload")
+                    help="default run (shell) only: leave out the blocks of the other workloads (R-MAT scale 22, 3-D grid, Erdos-Renyi)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (spgemm_set_option), e.g. --opt row_groups=0")
     ap.add_argument("--dist", action="store_true",
