@@ -527,29 +527,67 @@ int oracle_max_threads(void) {
 }
 
 /*
- * Test-run diagnostics (no counterpart in the reference): a SIGABRT handler that writes the NATIVE
- * call stack of the aborting thread to standard error before the handler that was installed
- * before it runs (Python's faulthandler shows Python frames only, and of every thread alike, so an
- * abort raised inside a C library or by a runtime thread cannot be told apart from the log).
+ * Test-run diagnostics (no counterpart in the reference): a handler for SIGABRT, SIGSEGV, SIGBUS,
+ * SIGFPE and SIGILL that writes the signal, the faulting address, the id and name of the thread the
+ * signal was delivered to and that thread's NATIVE call stack to standard error, then hands over to
+ * the handler that was installed before it (Python's faulthandler shows Python frames only, and of
+ * every thread alike, so a fault raised inside a C library or by a runtime thread cannot be told
+ * apart from the log).
  */
-static struct sigaction abort_prev;
-static void abort_trace_handler(int sig) {
-  static const char head[] = "\n--- SIGABRT: native stack of the aborting thread ---\n";
-  void *frames[64];
-  ssize_t ignored = write(2, head, sizeof(head) - 1);
+#include <sys/prctl.h>
+#include <sys/syscall.h>
+#define N_TRACED 5
+static const int traced_sig[N_TRACED] = {SIGABRT, SIGSEGV, SIGBUS, SIGFPE, SIGILL};
+static struct sigaction traced_prev[N_TRACED];
+static void put_str(const char *s) {
+  ssize_t ignored = write(2, s, strlen(s));
   (void)ignored;
+}
+static void put_hex(uint64_t v) {
+  char buf[19] = "0x";
+  for (int i = 0; i < 16; ++i)
+    buf[2 + i] = "0123456789abcdef"[(v >> (60 - 4 * i)) & 15];
+  buf[18] = 0;
+  put_str(buf);
+}
+static void fault_trace_handler(int sig, siginfo_t *info, void *uctx) {
+  void *frames[64];
+  char name[17] = {0};
+  (void)uctx;
+  put_str("\n--- fatal signal ");
+  put_hex((uint64_t)sig);
+  put_str(" at address ");
+  put_hex((uint64_t)(uintptr_t)(info ? info->si_addr : 0));
+  put_str(", thread ");
+  put_hex((uint64_t)syscall(SYS_gettid));
+  put_str(" of process ");
+  put_hex((uint64_t)getpid());
+  prctl(PR_GET_NAME, name, 0, 0, 0);
+  put_str(" named '");
+  put_str(name);
+  put_str("': native stack ---\n");
   int n = backtrace(frames, 64);
   backtrace_symbols_fd(frames, n, 2);
-  sigaction(SIGABRT, &abort_prev, NULL); /* then whoever was there before (faulthandler, or the default) */
+  /* then whoever was there before (faulthandler, or the default action) */
+  for (int i = 0; i < N_TRACED; ++i)
+    if (traced_sig[i] == sig)
+      sigaction(sig, &traced_prev[i], NULL);
   raise(sig);
 }
 int oracle_install_abort_trace(void) {
   struct sigaction sa;
   void *warm[4];
+  int rc = 0;
+  static int installed = 0;
+  if (installed) /* a second install would save this handler as its own predecessor */
+    return 0;
+  installed = 1;
   backtrace(warm, 4); /* loads libgcc's unwinder now, not inside the handler */
   memset(&sa, 0, sizeof(sa));
-  sa.sa_handler = abort_trace_handler;
+  sa.sa_sigaction = fault_trace_handler;
   sigemptyset(&sa.sa_mask);
-  sa.sa_flags = SA_NODEFER;
-  return sigaction(SIGABRT, &sa, &abort_prev);
+  sa.sa_flags = SA_NODEFER | SA_SIGINFO | SA_ONSTACK;
+  for (int i = 0; i < N_TRACED; ++i)
+    rc |= sigaction(traced_sig[i], &sa, &traced_prev[i]);
+  return rc;
 }

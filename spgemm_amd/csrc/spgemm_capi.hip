@@ -2262,11 +2262,15 @@ extern "C" int spgemm_upload_sections(spgemm_ctx *ctx, uint32_t n, const uint32_
   // the row lengths of all sections in one piece (the blob holds row pointers), then one copy per array and section
   std::vector<uint32_t> len(rows_total);
   uint64_t ro = 0, zo = 0;
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = 0; i < n; ++i) {  // every check before the first copy: no return with copies in flight
     for (uint32_t r = 0; r < rows[i]; ++r) {
       if (h_row_ptr[i][r + 1] < h_row_ptr[i][r]) return fail(SPGEMM_ERR_INVALID, "section %u: row pointer decreases at row %u", i, r);
       len[ro + r] = h_row_ptr[i][r + 1] - h_row_ptr[i][r];
     }
+    ro += rows[i];
+  }
+  ro = 0;
+  for (uint32_t i = 0; i < n; ++i) {
     if (nnz[i]) {
       HIP_TRY(hipMemcpyAsync(d_col_idx_out + zo, h_col_idx[i], (size_t)nnz[i] * 4, hipMemcpyHostToDevice, ctx->stream));
       HIP_TRY(hipMemcpyAsync(d_val_out + zo, h_val[i], (size_t)nnz[i] * 8, hipMemcpyHostToDevice, ctx->stream));

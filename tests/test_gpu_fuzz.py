@@ -2,6 +2,8 @@
 row-binning options so that every kernel family (window, row groups, LDS hash, workgroup hash,
 big-row windows and slices, unsorted-B fallback) sees them; each result is compared bit for bit
 with the CPU oracle.  Seeds are fixed: a failure names its case."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,7 +93,8 @@ def make_case(seed):
     return A, B, opts
 
 
-N_CASES = 96
+# SPGEMM_FUZZ_CASES: more seeds for a one-off sweep (the suite runs the first 96)
+N_CASES = int(os.environ.get("SPGEMM_FUZZ_CASES", "96"))
 
 
 @pytest.mark.parametrize("seed", range(N_CASES))
