@@ -126,6 +126,48 @@ __host__ __device__ inline size_t grp_region(bool compact, uint32_t words, uint3
 __host__ __device__ inline bool grp_use_compact(uint32_t words, uint32_t cap, uint32_t gmax, uint32_t alen) {
   return (size_t)words * 8u * 3u > grp_region(false, words, cap, gmax, alen);
 }
+// The rank table (column -> output position) of a group, built from its SORTED column list: lane l of
+// register u holds the column at position p = 64 u + l.  Columns of one 32-column word sit in
+// neighbouring lanes, so the first lane of a word knows the word's "outputs before" (its own p), the
+// number of words that began before it is a population count over the lanes (its index among the
+// words with outputs, for the two-level form), and the first lane of a top word knows that word's
+// "words before": one round of LDS stores and ORs, no scan over the table and no look-up while it
+// is built.  top[] / cw[] must be zero (compact: cw[0 .. n), flat: all words of the hull) and fenced.
+// emit(p, c) is called by the lanes that hold a column.  Returns the number of words with outputs.
+template <bool COMPACT, uint32_t TCN, class Emit>
+__device__ __forceinline__ uint32_t grp_rank_build(const uint32_t (&tc)[TCN], uint32_t n, uint32_t base, uint32_t lane,
+                                                   uint32_t *top32, uint32_t *cw32, Emit emit) {
+  uint32_t ncw = 0, prev_wi = 0xFFFFFFFFu; // wave-uniform: words so far, word of the last column so far
+  const uint64_t le = (2ull << lane) - 1ull; // lanes up to this one
+#pragma unroll
+  for (uint32_t u = 0; u < TCN; ++u) {
+    if (64u * u < n) { // wave-uniform
+      const uint32_t p = 64u * u + lane;
+      const bool act = p < n;
+      const uint32_t c = tc[u];
+      if (act) emit(p, c);
+      const uint32_t cc = c - base, wi = cc >> 5;
+      const uint32_t wi_before = dpp_move<0x138>(prev_wi, wi); // the lane before (wave_shr:1); lane 0: the register before
+      const bool word_start = act && wi != wi_before;
+      const uint64_t bal = __ballot(word_start);
+      if constexpr (COMPACT) {
+        const uint32_t ci = ncw + (uint32_t)__popcll(bal & le) - 1u; // (the first column starts a word: never below zero)
+        if (act) atomicOr(&cw32[ci * 2u], 1u << (cc & 31u));
+        if (word_start) {
+          cw32[ci * 2u + 1u] = p;
+          atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
+          if ((wi >> 5) != (wi_before >> 5)) top32[(wi >> 5) * 2u + 1u] = ci;
+        }
+      } else {
+        if (act) atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
+        if (word_start) cw32[wi * 2u + 1u] = p;
+      }
+      ncw += (uint32_t)__popcll(bal);
+      prev_wi = (uint32_t)__builtin_amdgcn_readlane((int)wi, 63);
+    }
+  }
+  return ncw;
+}
 template <int TIER, bool COMPACT, bool TAIL = false> // TAIL: see RowWalk
 __global__ void __launch_bounds__(256)
     k_num_window_grp(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, NumOut o,
@@ -188,53 +230,17 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (uint32_t u = 0; u < TCN; ++u) tc[u] = 64u * u + lane < n ? tin[64u * u + lane] : 0u;
   lds_fence();
+  grp_rank_build<COMPACT, TCN>(tc, n, base, lane, top32, cw32, [&](uint32_t p, uint32_t c) {
 #pragma unroll
-  for (uint32_t u = 0; u < TCN; ++u) {
-    const uint32_t p = 64u * u + lane;
-    if (64u * u < n && p < n) { // (the first test is wave-uniform)
-      const uint32_t c = tc[u];
-#pragma unroll
-      for (uint32_t j = 0; j < GRP_MAX; ++j)
-        if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
-      const uint32_t cc = c - base, wi = cc >> 5;
-      if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
-      else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
-    }
-  }
-  lds_fence();
-  uint32_t ncw = nw;
+    for (uint32_t j = 0; j < GRP_MAX; ++j)
+      if (j < cnt) o.c_col[readlane64(my_off, j) + p] = c;
+  });
   // index in cw[] of the 32-column word wi (compact: a word that holds an output)
   auto compact_word = [&](uint32_t wi) {
     if constexpr (!COMPACT) return wi;
     const uint64_t t = top[wi >> 5];
     return (uint32_t)(t >> 32) + __popc((uint32_t)t & ((1u << (wi & 31u)) - 1u));
   };
-  if constexpr (COMPACT) {
-    ncw = 0;
-    for (uint32_t r0 = 0; r0 < ntop; r0 += 64) {
-      const uint32_t ti = r0 + lane;
-      const uint32_t pc = ti < ntop ? __popc(top32[ti * 2u]) : 0u;
-      const uint32_t incl = group_incl_scan<64>(pc);
-      if (ti < ntop) top32[ti * 2u + 1u] = ncw + incl - pc;
-      ncw += group_last<64>(incl);
-    }
-    lds_fence();
-#pragma unroll
-    for (uint32_t u = 0; u < TCN; ++u)
-      if (64u * u < n && 64u * u + lane < n) {
-        const uint32_t cc = tc[u] - base;
-        atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
-      }
-    lds_fence();
-  }
-  uint32_t carry = 0;
-  for (uint32_t r0 = 0; r0 < ncw; r0 += 64) {
-    const uint32_t ci = r0 + lane;
-    const uint32_t pc = ci < ncw ? __popc(cw32[ci * 2u]) : 0u;
-    const uint32_t incl = group_incl_scan<64>(pc);
-    if (ci < ncw) cw32[ci * 2u + 1u] = carry + incl - pc;
-    carry += group_last<64>(incl);
-  }
   lds_fence();
   walk.run(A, B, lane, [&](uint32_t c, double bv, double, uint32_t apos) {
     const uint32_t cc = c - base;
@@ -375,7 +381,7 @@ __global__ void __launch_bounds__(256)
     const uint64_t a0 = readlane64(st_a0, g), coff = readlane64(st_coff, g);
     const uint32_t len_a = rl32(st_len, g);
     cur.len_a = len_a; // (a row without entries cannot be here; the loads above assumed one entry at least)
-    cur.finish(lane);
+    cur.template finish<RMAX>(lane);
     // the next group's description: bounds of its B rows now, column indices of the group after it
     nxt.issue_b(B, same_bits);
     RowRuns<WIDE> aft;
@@ -410,52 +416,16 @@ __global__ void __launch_bounds__(256)
     RunPipe<RMAX, true, GRP_RUN_SLOTS, WIDE> pipe;
     pipe.begin(B, cur, lane);
     lds_fence();
+    grp_rank_build<COMPACT, TCN>(tc, n, base, lane, top32, cw32, [&](uint32_t p, uint32_t c) {
 #pragma unroll
-    for (uint32_t u = 0; u < TCN; ++u) {
-      const uint32_t p = 64u * u + lane;
-      if (64u * u < n && p < n) {
-        const uint32_t c = tc[u];
-#pragma unroll
-        for (uint32_t j = 0; j < gmaxc; ++j)
-          if (j < cnt) o.c_col[coff + (uint64_t)j * n + p] = c;
-        const uint32_t cc = c - base, wi = cc >> 5;
-        if constexpr (COMPACT) atomicOr(&top32[(wi >> 5) * 2u], 1u << (wi & 31u));
-        else atomicOr(&cw32[wi * 2u], 1u << (cc & 31u));
-      }
-    }
-    lds_fence();
-    uint32_t ncw = nw;
+      for (uint32_t j = 0; j < gmaxc; ++j)
+        if (j < cnt) o.c_col[coff + (uint64_t)j * n + p] = c;
+    });
     auto compact_word = [&](uint32_t wi) {
       if constexpr (!COMPACT) return wi;
       const uint64_t t = top[wi >> 5];
       return (uint32_t)(t >> 32) + __popc((uint32_t)t & ((1u << (wi & 31u)) - 1u));
     };
-    if constexpr (COMPACT) {
-      ncw = 0;
-      for (uint32_t r0 = 0; r0 < ntop; r0 += 64) {
-        const uint32_t ti = r0 + lane;
-        const uint32_t pc = ti < ntop ? __popc(top32[ti * 2u]) : 0u;
-        const uint32_t incl = group_incl_scan<64>(pc);
-        if (ti < ntop) top32[ti * 2u + 1u] = ncw + incl - pc;
-        ncw += group_last<64>(incl);
-      }
-      lds_fence();
-#pragma unroll
-      for (uint32_t u = 0; u < TCN; ++u)
-        if (64u * u < n && 64u * u + lane < n) {
-          const uint32_t cc = tc[u] - base;
-          atomicOr(&cw32[compact_word(cc >> 5) * 2u], 1u << (cc & 31u));
-        }
-      lds_fence();
-    }
-    uint32_t carry = 0;
-    for (uint32_t r0 = 0; r0 < ncw; r0 += 64) {
-      const uint32_t ci = r0 + lane;
-      const uint32_t pc = ci < ncw ? __popc(cw32[ci * 2u]) : 0u;
-      const uint32_t incl = group_incl_scan<64>(pc);
-      if (ci < ncw) cw32[ci * 2u + 1u] = carry + incl - pc;
-      carry += group_last<64>(incl);
-    }
     lds_fence();
     // the next group's column list (this group's is used up)
     load_tc(g1, tc);

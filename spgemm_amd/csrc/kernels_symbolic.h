@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256)
       // registers (RowRuns), only the first row of every run is walked, and the columns of
       // SYM_RUN_SLOTS - 1 of them are in flight while one is ORed in
       RowRuns<true> runs;
-      runs.load(A, B, same_bits, a0, (uint32_t)(a1 - a0), lane);
+      runs.load<255>(A, B, same_bits, a0, (uint32_t)(a1 - a0), lane);
       RunPipe<255, false, SYM_RUN_SLOTS, true> pipe;
       pipe.begin(B, runs, lane);
       pipe.run(B, runs, lane, [&](const RunInfo &, const RunVec<1> &v) { mark(v.ok ? v.col : EMPTY_KEY, 0.0, 0.0, 0u); });
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256)
     const bool is_long = rl32(st_long, g) != 0u;
     for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
     cur.len_a = rl32(st_len, g); // (a row without entries cannot be here; the loads above assumed one entry at least)
-    cur.finish(lane);
+    cur.finish<255>(lane);
     nxt.issue_b(B, same_bits);
     RowRuns<true> aft;
     aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);

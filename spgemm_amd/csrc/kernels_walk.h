@@ -216,10 +216,17 @@ __device__ __forceinline__ void wave_row_walk(const Csr &A, const Csr &B, uint32
 //
 // The description of the whole A row lives in registers: lane t holds, for the entries t and 64 + t,
 // the start and the length of the B row and whether the entry continues a run; it is loaded once,
-// when the kernel starts, and the units are then enumerated with lane reads only.  No load of the
-// walk depends on another load after that, so the B entries of DEPTH units are in flight while
-// one is consumed (the kernels that walk a row through dependent scalar loads have one stage in
-// flight and are bound by the latency of that chain).
+// when the kernel starts.  No load of the walk depends on another load after that, so the B
+// entries of DEPTH units are in flight while one is consumed (the kernels that walk a row through
+// dependent scalar loads have one stage in flight and are bound by the latency of that chain).
+//
+// The units are laid out by the vector unit, 64 at a time, lane u holding unit u (its rows' start,
+// length, first entry, row count and chunk): a prefix sum of the chunk counts of the entries that
+// begin a unit's rows, and a search of every lane for its entry over those sums.  Handing out a unit
+// is then four lane reads by a counter.  (Enumerated on the scalar unit - next entry that begins a
+// run, its length, chunk counter, two units of state in flight - the walk cost about a hundred scalar
+// instructions per unit, twice what the vector unit spent on the unit's products: these kernels
+// are bound by the instructions they issue, the scalar ones included.)
 struct RunInfo { // wave-uniform
   uint64_t p0;  // start of the first B row of the run
   uint32_t L;   // entries of each of its B rows
@@ -239,10 +246,15 @@ template <bool WIDE> struct RowRuns {
   uint32_t len_lo, len_hi;
   uint64_t start_lo, start_hi; // wave-uniform: entries that begin a run
   uint32_t len_a;
-  // iterator (wave-uniform)
-  uint32_t t, run_end, rl, L, chunk;
-  uint64_t p0;
-  bool done;
+  // rs_lo / rs_hi (wave-uniform): the entries that begin a unit's rows: every entry that begins a
+  // run and, in a run of more than RMAX rows, every RMAX-th entry after it
+  uint64_t rs_lo, rs_hi;
+  // the units: of one half of the entries (ph = 0: entries 0..63, 1: 64..127) at a time, 64 per table
+  uint32_t ph, ph_tot, ph_done; // wave-uniform: half, its units, those of them laid out so far
+  uint32_t ph_base, ph_rl;      // per lane (entry): units before the entry's in this half, rows of its unit
+  uint64_t u_p0;                // per lane (unit of the table): start of the first of its B rows
+  uint32_t u_L, u_meta;         // entries per row; first entry | rows << 8 | chunk << 16
+  uint32_t nu, ui;              // wave-uniform: units in the table, next one to hand out
 
   // The description is loaded in two dependent steps, which a kernel that walks several rows one
   // after the other issues a row (and two rows) ahead: issue_a() loads the row's column indices k,
@@ -269,7 +281,8 @@ template <bool WIDE> struct RowRuns {
       bits_hi = same_bits[k_hi >> 5];
     }
   }
-  __device__ __forceinline__ void finish(uint32_t lane) {
+  // RMAX: rows a unit takes at most (128 or more: a run is never cut)
+  template <int RMAX> __device__ __forceinline__ void finish(uint32_t lane) {
     const uint32_t len = len_a;
     len_lo = lane < len ? (uint32_t)min(p1_lo - p0_lo, (uint64_t)0xFFFFFFFFu) : 0u;
     // an entry continues a run when it selects the row after the one its predecessor selects and
@@ -288,57 +301,104 @@ template <bool WIDE> struct RowRuns {
       const bool cont_hi = 64u + lane < len && ((bits_hi >> (k_hi & 31u)) & 1u) && k_hi == kp_hi + 1u;
       start_hi = __ballot(64u + lane < len && !cont_hi);
     }
-    t = 0; run_end = 0; rl = 0; L = 0; chunk = 0; p0 = 0;
-    done = len == 0;
+    rs_lo = start_lo;
+    rs_hi = start_hi;
+    if constexpr (RMAX < 128) {
+      // where the lane's run began (entry 0 begins one, so the masks below are never empty for an entry of the row)
+      const uint64_t le = (2ull << lane) - 1ull;
+      const uint32_t s_lo = 63u - (uint32_t)__clzll((long long)((start_lo & le) | 1ull));
+      rs_lo = __ballot(lane < len && (lane - s_lo) % (uint32_t)RMAX == 0u);
+      if constexpr (WIDE) {
+        const uint64_t mh = start_hi & le;
+        const uint32_t s_hi = mh ? 127u - (uint32_t)__clzll((long long)mh) : 63u - (uint32_t)__clzll((long long)(start_lo | 1ull));
+        rs_hi = __ballot(64u + lane < len && (64u + lane - s_hi) % (uint32_t)RMAX == 0u);
+      }
+    }
+    ph = 0; ph_tot = 0; ph_done = 0; nu = 0; ui = 0;
+    if (len) {
+      start_half(lane);
+      refill(lane);
+    }
+  }
+  // prefix sums of the chunk counts of half ph's entries that begin a unit's rows
+  __device__ __forceinline__ void start_half(uint32_t lane) {
+    const bool hi = WIDE && ph != 0u; // wave-uniform
+    const uint64_t rs = hi ? rs_hi : rs_lo;
+    const uint32_t off = hi ? 64u : 0u;
+    // the entry after the unit's rows: the next one that begins rows, in this half, the other one, or the row's end
+    const uint32_t tail = ((!hi && WIDE && rs_hi) ? 64u + (uint32_t)__builtin_ctzll(rs_hi) : len_a) - off;
+    const uint64_t after = lane < 63u ? rs >> (lane + 1u) : 0ull;
+    const uint32_t tn = after ? lane + 1u + (uint32_t)__builtin_ctzll(after) : tail;
+    ph_rl = tn - lane;
+    const uint32_t len = hi ? len_hi : len_lo;
+    const uint32_t nch = ((rs >> lane) & 1ull) ? (len + 63u) >> 6 : 0u;
+    const uint32_t incl = group_incl_scan<64>(nch);
+    ph_base = incl - nch;
+    ph_tot = group_last<64>(incl);
+    ph_done = 0;
+  }
+  // the next table of up to 64 units; nu == 0: the row has no more
+  __device__ __forceinline__ void refill(uint32_t lane) {
+    ui = 0;
+    nu = 0;
+    while (ph_done >= ph_tot) { // (wave-uniform) this half is used up
+      if (!WIDE || ph != 0u) return;
+      ph = 1u;
+      start_half(lane);
+      if (rs_hi == 0ull) return;
+    }
+    const bool hi = WIDE && ph != 0u;
+    const uint32_t u = ph_done + lane;
+    // the unit's entry: the last one with at most u units before it (the sums do not decrease, and an
+    // entry that begins no rows, or rows without entries, has the sum of the entry after it)
+    uint32_t t = 0;
+#pragma unroll
+    for (uint32_t s = 32; s > 0; s >>= 1) {
+      const uint32_t b = __shfl(ph_base, (int)(t + s), 64);
+      if (b <= u) t += s;
+    }
+    const uint32_t chunk = u - __shfl(ph_base, (int)t, 64);
+    const uint32_t rows = __shfl(ph_rl, (int)t, 64);
+    if (hi) {
+      u_p0 = __shfl(p0_hi, (int)t, 64);
+      u_L = __shfl(len_hi, (int)t, 64);
+    } else {
+      u_p0 = __shfl(p0_lo, (int)t, 64);
+      u_L = __shfl(len_lo, (int)t, 64);
+    }
+    u_meta = (t + (hi ? 64u : 0u)) | (rows << 8) | (chunk << 16);
+    nu = min(64u, ph_tot - ph_done);
+    ph_done += nu;
   }
   // the whole description at once, for A row [a0, a0 + len); len <= 64 (128 when WIDE); len == 0: no unit
+  template <int RMAX>
   __device__ __forceinline__ void load(const Csr &A, const Csr &B, const uint32_t *__restrict__ same_bits, uint64_t a0,
                                        uint32_t len, uint32_t lane) {
     if (len == 0) { // wave-uniform
-      len_a = 0; done = true; rl = 0; L = 0; chunk = 0; t = 0; run_end = 0; p0 = 0; start_lo = start_hi = 0;
+      len_a = 0; start_lo = start_hi = 0; rs_lo = rs_hi = 0; ph = 0; ph_tot = 0; ph_done = 0; nu = 0; ui = 0;
       p0_lo = p0_hi = 0; len_lo = len_hi = 0;
       return;
     }
     issue_a(A, a0, len, lane);
     issue_b(B, same_bits);
-    finish(lane);
+    finish<RMAX>(lane);
   }
-  // first entry >= from that begins a run (len_a when there is none)
-  __device__ __forceinline__ uint32_t next_start(uint32_t from) const {
-    if (from < 64u) {
-      const uint64_t m = start_lo >> from;
-      if (m) return from + (uint32_t)__builtin_ctzll(m);
-      from = 64u;
-    }
-    if constexpr (WIDE) {
-      if (from < 128u) {
-        const uint64_t m = start_hi >> (from - 64u);
-        if (m) return from + (uint32_t)__builtin_ctzll(m);
-      }
-    }
-    return len_a;
-  }
-  // the next unit, RMAX rows of a run at most
-  template <int RMAX> __device__ __forceinline__ RunInfo next() {
+  // the next unit (RMAX: as given to finish())
+  template <int RMAX> __device__ __forceinline__ RunInfo next(uint32_t lane) {
     RunInfo r{0, 0, 1, 0, 0, false};
-    if (done) return r;
-    if (rl != 0 && (chunk + 1u) * 64u < L) { // more columns of the same rows
-      ++chunk;
-    } else {
-      t += rl; // (0 before the first unit)
-      if (t >= len_a) { done = true; return r; }
-      if (t >= run_end) run_end = next_start(t + 1u);
-      rl = min(run_end - t, (uint32_t)RMAX);
-      chunk = 0;
-      if constexpr (WIDE) {
-        if (t < 64u) { p0 = readlane64(p0_lo, t); L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t); }
-        else { p0 = readlane64(p0_hi, t - 64u); L = (uint32_t)__builtin_amdgcn_readlane((int)len_hi, (int)(t - 64u)); }
-      } else {
-        p0 = readlane64(p0_lo, t);
-        L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t);
-      }
+    if (ui >= nu) { // wave-uniform; the table is used up (or there never was one)
+      if (nu == 0u) return r;
+      refill(lane);
+      if (nu == 0u) return r;
     }
-    r.p0 = p0; r.L = L; r.rl = rl; r.t0 = t; r.chunk = chunk; r.valid = true;
+    const uint32_t i = ui++;
+    const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)u_meta, (int)i);
+    r.p0 = readlane64(u_p0, i);
+    r.L = (uint32_t)__builtin_amdgcn_readlane((int)u_L, (int)i);
+    r.t0 = meta & 0xFFu;
+    r.rl = (meta >> 8) & 0xFFu;
+    r.chunk = meta >> 16;
+    r.valid = true;
     return r;
   }
 };
@@ -356,15 +416,13 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
   const uint32_t jj = (v.ok ? j : 0u) & 0xFFFFFu;
   v.col = (B.col + base)[jj];
   if constexpr (WITH_VAL) {
+    // one base address on the scalar unit; a row of the run is a 32-bit offset of the lane (a run has at
+    // most 8 rows of at most 65,536 entries: the mask tells the compiler that the byte offset fits)
+    const double *vb = B.val + base;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const uint32_t rr = min((uint32_t)r, s.rl - 1u);
-      // (wave-uniform: the row's base address is kept on the scalar unit, the lane adds a 32-bit offset)
-      const uint64_t rowp = (uint64_t)(uintptr_t)(B.val + base + (uint64_t)rr * s.L);
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rowp);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rowp >> 32));
-      typedef const double __attribute__((address_space(1))) *global_f64_ptr; // (global memory, not a generic address)
-      v.bv[r] = ((global_f64_ptr)(uintptr_t)(((uint64_t)hi << 32) | lo))[jj];
+      v.bv[r] = vb[(jj + rr * s.L) & 0xFFFFFu];
     }
   }
 }
@@ -378,7 +436,7 @@ template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
   __device__ __forceinline__ void begin(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      info[s] = rr.template next<RMAX>();
+      info[s] = rr.template next<RMAX>(lane);
       run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
     }
   }
@@ -388,7 +446,7 @@ template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
       for (int s = 0; s < SLOTS; ++s) {
         if (!info[s].valid) return; // the units come in order: the first empty slot ends the walk
         f(info[s], vec[s]);
-        info[s] = rr.template next<RMAX>();
+        info[s] = rr.template next<RMAX>(lane);
         run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
       }
     }
