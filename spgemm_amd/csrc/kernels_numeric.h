@@ -291,6 +291,9 @@ __global__ void __launch_bounds__(256)
 #ifndef SG_GRP_ALDS
 #define SG_GRP_ALDS 0
 #endif
+#ifndef SG_GRP_WPE
+#define SG_GRP_WPE 1
+#endif
 constexpr int GRP_RUN_SLOTS = SG_GRP_SLOTS;
 // SG_GRP_ALDS: the A values of the group's rows are staged in LDS and read back as broadcasts (one LDS
 // read per row of the group and B row) instead of being handed from a lane to the scalar unit (two
@@ -303,14 +306,15 @@ constexpr bool GRP_RUN_ALDS = SG_GRP_ALDS != 0;
 // the next B row behind the first use of this one's, so that they land during its additions, lost
 // on both (scalar loads return in any order: every wait is for all that are out).
 #ifndef SG_GRP_ASCALAR
-#define SG_GRP_ASCALAR 2
+#define SG_GRP_ASCALAR 1
 #endif
 __host__ __device__ inline size_t grp_run_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, bool wide) {
   return grp_region(compact, words, cap, gmax, 0) + (GRP_RUN_ALDS ? (size_t)gmax * (wide ? 128u : 64u) * 8u : 0u);
 }
 // TCN: registers of 64 columns that hold a group's column list (cap <= 64 * TCN)
+// (the narrow groups need little LDS: registers for six wavefronts per SIMD keep the LDS the limit)
 template <bool WIDE, bool COMPACT, int RMAX, int GMAX, int TCN_>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
     k_num_grp_run(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, const uint32_t *__restrict__ same_bits,
                   RowMeta m, NumOut o, uint32_t words, uint32_t cap, uint32_t wpb, uint32_t rpw) {
   // A wavefront takes rpw (<= 64) consecutive groups of its bin, one after the other.  What a group
@@ -347,24 +351,26 @@ __global__ void __launch_bounds__(256)
   static_assert(GMAX <= (int)(WIDE ? GRP_MAX_WIDE : GRP_MAX), "more rows than a group can have");
   // row state of the wavefront's groups: lane i holds group i's (the lanes past the last group repeat it)
   const uint32_t st_row = rows[first + min(lane, ng - 1u)];
-  const uint32_t st_cnt = min((uint32_t)m.gcnt[st_row], gmax);
-  const uint32_t st_cmin = m.cmin[st_row], st_cmax = m.cmax[st_row], st_n = m.nnz[st_row];
+  const uint32_t st_cmin = m.cmin[st_row], st_cmax = m.cmax[st_row];
   const uint64_t st_toff = m.t_off[st_row], st_a0 = A.ptr[st_row], st_coff = o.c_ptr[st_row];
-  const uint32_t st_len = (uint32_t)min(A.ptr[(uint64_t)st_row + 1u] - st_a0, (uint64_t)ALEN);
+  // rows of the group | entries of its A rows << 8 | outputs << 16, in one register
+  const uint32_t st_pack = min((uint32_t)m.gcnt[st_row], gmax) | ((uint32_t)min(A.ptr[(uint64_t)st_row + 1u] - st_a0, (uint64_t)ALEN) << 8) |
+                           ((uint32_t)m.nnz[st_row] << 16);
   auto rl32 = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
   constexpr uint32_t TCN = TCN_;
   // the group's column list; a lane past its end re-reads the last entry (n >= 1 for every row of this bin)
   auto load_tc = [&](uint32_t g, uint32_t (&tc)[TCN]) {
     const uint32_t *tin = m.temp_cols + readlane64(st_toff, g);
-    const uint32_t n = rl32(st_n, g);
+    const uint32_t n = rl32(st_pack, g) >> 16;
 #pragma unroll
     for (uint32_t u = 0; u < TCN; ++u) tc[u] = tin[min(64u * u + lane, n - 1u)];
   };
   RowRuns<WIDE> cur, nxt;
-  cur.issue_a(A, readlane64(st_a0, 0), max(rl32(st_len, 0), 1u), lane);
+  auto len_of = [&](uint32_t g) { return (rl32(st_pack, g) >> 8) & 0xFFu; };
+  cur.issue_a(A, readlane64(st_a0, 0), max(len_of(0), 1u), lane);
   {
     const uint32_t g1 = min(1u, ng - 1u);
-    nxt.issue_a(A, readlane64(st_a0, g1), max(rl32(st_len, g1), 1u), lane);
+    nxt.issue_a(A, readlane64(st_a0, g1), max(len_of(g1), 1u), lane);
   }
   cur.issue_b(B, same_bits);
   uint32_t tc[TCN];
@@ -374,18 +380,19 @@ __global__ void __launch_bounds__(256)
   for (uint32_t g = 0; g < ng; ++g) {
     const uint32_t g1 = min(g + 1u, ng - 1u), g2 = min(g + 2u, ng - 1u);
     // this group's scalars
-    const uint32_t cnt = rl32(st_cnt, g);
+    const uint32_t pack = rl32(st_pack, g);
+    const uint32_t cnt = pack & 0xFFu;
     const uint32_t base = rl32(st_cmin, g) & ~31u;
     const uint32_t nw = ((rl32(st_cmax, g) - base) >> 5) + 1u;
-    const uint32_t n = rl32(st_n, g);
+    const uint32_t n = pack >> 16;
     const uint64_t a0 = readlane64(st_a0, g), coff = readlane64(st_coff, g);
-    const uint32_t len_a = rl32(st_len, g);
+    const uint32_t len_a = (pack >> 8) & 0xFFu;
     cur.len_a = len_a; // (a row without entries cannot be here; the loads above assumed one entry at least)
     cur.template finish<RMAX>(lane);
     // the next group's description: bounds of its B rows now, column indices of the group after it
     nxt.issue_b(B, same_bits);
     RowRuns<WIDE> aft;
-    aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);
+    aft.issue_a(A, readlane64(st_a0, g2), max(len_of(g2), 1u), lane);
     GR_STAMP(1) // waited for this group's description
     const uint32_t ntop = (nw + 31u) >> 5;
     if constexpr (COMPACT) {
@@ -432,10 +439,15 @@ __global__ void __launch_bounds__(256)
     GR_STAMP(2) // bitmap and prefix counts built, columns of C stored
     // value of A entry t of the group's row j (t wave-uniform)
     constexpr bool GRP_RUN_ASCALAR = SG_GRP_ASCALAR == 1 || (SG_GRP_ASCALAR == 2 && WIDE);
-    const auto a_val_s = scalar_view(A.val);
-    const uint64_t a_base_s = a0; // (wave-uniform: it came through v_readlane)
+    // the rows' values through the scalar unit: one base address per row (a row past the group's end
+    // reads row 0: its sums are never written out) and a 32-bit entry number, which the compiler turns
+    // into loads of the form base + scalar offset + constant: the values of a run's entries, which lie
+    // side by side, arrive in one or two loads per row, without an address computation each
+    const_as_ptr<double> a_row[gmaxc];
+#pragma unroll
+    for (uint32_t j = 0; j < gmaxc; ++j) a_row[j] = scalar_view(A.val + a0 + (uint64_t)(j < cnt ? j : 0u) * len_a);
     auto a_of = [&](uint32_t j, uint32_t t) {
-      if constexpr (GRP_RUN_ASCALAR) return a_val_s[a_base_s + (uint64_t)j * len_a + (uint32_t)__builtin_amdgcn_readfirstlane((int)t)];
+      if constexpr (GRP_RUN_ASCALAR) return a_row[j][(uint32_t)__builtin_amdgcn_readfirstlane((int)t) & 0xFFu]; // (t < 128)
       else if constexpr (GRP_RUN_ALDS) return avals[j * ALEN + t];
       else if constexpr (WIDE) return t < 64u ? readlane_f64(av_lo[j], t) : readlane_f64(av_hi[j], t - 64u);
       else return readlane_f64(av_lo[j], t);
@@ -450,6 +462,18 @@ __global__ void __launch_bounds__(256)
         if (ri.rl == 1u) { // wave-uniform
 #pragma unroll
           for (uint32_t j = 0; j < gmaxc; ++j) lds_add_f64(acc_at + j * cap, __dmul_rn(a_of(j, ri.t0), v.bv[0]));
+        } else if (GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX) { // a whole run: row after row, each row's values in one go
+          const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri.t0) & 0x7Fu; // (t0 < 128)
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) {
+            double a[RMAX];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) a[r] = a_row[j][tb + (uint32_t)r]; // (one masked entry number + constants: adjacent loads merge)
+            double acc = acc_at[j * cap];
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) acc = __dadd_rn(acc, __dmul_rn(a[r], v.bv[r]));
+            acc_at[j * cap] = acc;
+          }
         } else {
           double acc[gmaxc];
 #pragma unroll

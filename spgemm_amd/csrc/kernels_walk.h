@@ -251,7 +251,6 @@ template <bool WIDE> struct RowRuns {
   uint64_t rs_lo, rs_hi;
   // the units: of one half of the entries (ph = 0: entries 0..63, 1: 64..127) at a time, 64 per table
   uint32_t ph, ph_tot, ph_done; // wave-uniform: half, its units, those of them laid out so far
-  uint32_t ph_base, ph_rl;      // per lane (entry): units before the entry's in this half, rows of its unit
   uint64_t u_p0;                // per lane (unit of the table): start of the first of its B rows
   uint32_t u_L, u_meta;         // entries per row; first entry | rows << 8 | chunk << 16
   uint32_t nu, ui;              // wave-uniform: units in the table, next one to hand out
@@ -315,13 +314,12 @@ template <bool WIDE> struct RowRuns {
       }
     }
     ph = 0; ph_tot = 0; ph_done = 0; nu = 0; ui = 0;
-    if (len) {
-      start_half(lane);
-      refill(lane);
-    }
+    if (len) refill(lane);
   }
-  // prefix sums of the chunk counts of half ph's entries that begin a unit's rows
-  __device__ __forceinline__ void start_half(uint32_t lane) {
+  // prefix sums of the chunk counts of half ph's entries that begin a unit's rows (base: units before the
+  // entry's; rows: rows of its unit).  Recomputed by every refill: a second one is rare (more than 64
+  // units in a half), and the two registers would otherwise be held through the whole walk.
+  __device__ __forceinline__ void half_sums(uint32_t lane, uint32_t &base, uint32_t &rows) {
     const bool hi = WIDE && ph != 0u; // wave-uniform
     const uint64_t rs = hi ? rs_hi : rs_lo;
     const uint32_t off = hi ? 64u : 0u;
@@ -329,23 +327,25 @@ template <bool WIDE> struct RowRuns {
     const uint32_t tail = ((!hi && WIDE && rs_hi) ? 64u + (uint32_t)__builtin_ctzll(rs_hi) : len_a) - off;
     const uint64_t after = lane < 63u ? rs >> (lane + 1u) : 0ull;
     const uint32_t tn = after ? lane + 1u + (uint32_t)__builtin_ctzll(after) : tail;
-    ph_rl = tn - lane;
+    rows = tn - lane;
     const uint32_t len = hi ? len_hi : len_lo;
     const uint32_t nch = ((rs >> lane) & 1ull) ? (len + 63u) >> 6 : 0u;
     const uint32_t incl = group_incl_scan<64>(nch);
-    ph_base = incl - nch;
+    base = incl - nch;
     ph_tot = group_last<64>(incl);
-    ph_done = 0;
   }
   // the next table of up to 64 units; nu == 0: the row has no more
   __device__ __forceinline__ void refill(uint32_t lane) {
     ui = 0;
     nu = 0;
-    while (ph_done >= ph_tot) { // (wave-uniform) this half is used up
-      if (!WIDE || ph != 0u) return;
+    uint32_t ph_base, ph_rl;
+    half_sums(lane, ph_base, ph_rl);
+    if (ph_done >= ph_tot) { // (wave-uniform) this half is used up
+      if (!WIDE || ph != 0u || rs_hi == 0ull) return;
       ph = 1u;
-      start_half(lane);
-      if (rs_hi == 0ull) return;
+      ph_done = 0;
+      half_sums(lane, ph_base, ph_rl);
+      if (ph_tot == 0u) return;
     }
     const bool hi = WIDE && ph != 0u;
     const uint32_t u = ph_done + lane;
@@ -383,14 +383,12 @@ template <bool WIDE> struct RowRuns {
     issue_b(B, same_bits);
     finish<RMAX>(lane);
   }
-  // the next unit (RMAX: as given to finish())
-  template <int RMAX> __device__ __forceinline__ RunInfo next(uint32_t lane) {
+  // more units after those of the table
+  __device__ __forceinline__ bool more() const { return ph_done < ph_tot || (WIDE && ph == 0u && rs_hi != 0ull); }
+  // the next unit of the table (RMAX: as given to finish()); the caller refills an empty table
+  template <int RMAX> __device__ __forceinline__ RunInfo next() {
     RunInfo r{0, 0, 1, 0, 0, false};
-    if (ui >= nu) { // wave-uniform; the table is used up (or there never was one)
-      if (nu == 0u) return r;
-      refill(lane);
-      if (nu == 0u) return r;
-    }
+    if (ui >= nu) return r; // wave-uniform
     const uint32_t i = ui++;
     const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)u_meta, (int)i);
     r.p0 = readlane64(u_p0, i);
@@ -418,7 +416,12 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
   if constexpr (WITH_VAL) {
     // one base address on the scalar unit; a row of the run is a 32-bit offset of the lane (a run has at
     // most 8 rows of at most 65,536 entries: the mask tells the compiler that the byte offset fits)
-    const double *vb = B.val + base;
+    // (the lane reads say so to the compiler: scalar base + 32-bit lane offset, no 64-bit address per lane and row)
+    const uint64_t vbp = (uint64_t)(uintptr_t)(B.val + base);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vbp);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vbp >> 32));
+    typedef const double __attribute__((address_space(1))) *global_f64_ptr; // (global memory, not a generic address)
+    const global_f64_ptr vb = (global_f64_ptr)(uintptr_t)(((uint64_t)hi << 32) | lo);
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const uint32_t rr = min((uint32_t)r, s.rl - 1u);
@@ -436,19 +439,26 @@ template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
   __device__ __forceinline__ void begin(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      info[s] = rr.template next<RMAX>(lane);
+      info[s] = rr.template next<RMAX>();
       run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
     }
   }
   template <class F> __device__ __forceinline__ void run(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane, F f) {
     for (;;) {
+      // the units of one table; the pipeline drains at its end (once per 64 units)
+      for (bool open = true; open;) {
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (!info[s].valid) return; // the units come in order: the first empty slot ends the walk
-        f(info[s], vec[s]);
-        info[s] = rr.template next<RMAX>(lane);
-        run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+        for (int s = 0; s < SLOTS; ++s) {
+          if (!info[s].valid) { open = false; break; } // the units come in order: the first empty slot ends the table
+          f(info[s], vec[s]);
+          info[s] = rr.template next<RMAX>();
+          run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+        }
       }
+      if (!rr.more()) return;
+      rr.refill(lane);
+      if (rr.nu == 0u) return;
+      begin(B, rr, lane);
     }
   }
 };
