@@ -65,7 +65,10 @@ __device__ __forceinline__ void sym_window_finish(const Csr &A, const RowMeta &m
     m.num_key[row + lane] = (uint8_t)(grouped ? (lane == 0 ? gkey : KEY_NONE) : num_key_of(m.sym_key[row], n, m.hash_num_max));
   }
 }
-constexpr int SYM_RUN_SLOTS = 6;
+#ifndef SG_SYM_SLOTS
+#define SG_SYM_SLOTS 3
+#endif
+constexpr int SYM_RUN_SLOTS = SG_SYM_SLOTS; // units of the run walk whose columns are in flight
 template <bool FLAT, bool TAIL = false> // TAIL: see RowWalk (scalar walk only)
 __global__ void __launch_bounds__(256)
     k_sym_window(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m,
