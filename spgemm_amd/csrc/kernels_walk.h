@@ -414,18 +414,16 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
   const uint32_t jj = (v.ok ? j : 0u) & 0xFFFFFu;
   v.col = (B.col + base)[jj];
   if constexpr (WITH_VAL) {
-    // one base address on the scalar unit; a row of the run is a 32-bit offset of the lane (a run has at
-    // most 8 rows of at most 65,536 entries: the mask tells the compiler that the byte offset fits)
     // (the lane reads say so to the compiler: scalar base + 32-bit lane offset, no 64-bit address per lane and row)
     const uint64_t vbp = (uint64_t)(uintptr_t)(B.val + base);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vbp);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vbp >> 32));
     typedef const double __attribute__((address_space(1))) *global_f64_ptr; // (global memory, not a generic address)
-    const global_f64_ptr vb = (global_f64_ptr)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    const uint64_t vb = ((uint64_t)hi << 32) | lo;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
+    for (int r = 0; r < RMAX; ++r) { // a row of the run: its own base on the scalar unit, the lanes' offset is the same for all rows
       const uint32_t rr = min((uint32_t)r, s.rl - 1u);
-      v.bv[r] = vb[(jj + rr * s.L) & 0xFFFFFu];
+      v.bv[r] = ((global_f64_ptr)(uintptr_t)(vb + (uint64_t)(rr * s.L) * 8u))[jj];
     }
   }
 }
