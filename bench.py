@@ -102,12 +102,16 @@ def issue_bounds(sq, kernel_ms, n_cu=256, clock_ghz=2.4):
     if not sq:
         return None
     valu_ms = sq["SQ_INSTS_VALU"] * 4.0 / (4 * n_cu) / (clock_ghz * 1e6)
+    # a SIMD's issue slot comes round every 4 cycles and takes one scalar instruction at most
+    salu_ms = sq.get("SQ_INSTS_SALU", 0.0) * 4.0 / (4 * n_cu) / (clock_ghz * 1e6)
     lds_ms = sq["SQ_LDS_IDX_ACTIVE"] / n_cu / (clock_ghz * 1e6)
-    return {"valu_issue_ms": valu_ms, "lds_array_ms": lds_ms, "valu_frac_of_kernel_time": valu_ms / kernel_ms,
+    return {"valu_issue_ms": valu_ms, "salu_issue_ms": salu_ms, "lds_array_ms": lds_ms,
+            "valu_frac_of_kernel_time": valu_ms / kernel_ms, "salu_frac_of_kernel_time": salu_ms / kernel_ms,
             "lds_frac_of_kernel_time": lds_ms / kernel_ms, "valu_wave_instructions": sq["SQ_INSTS_VALU"],
+            "salu_wave_instructions": sq.get("SQ_INSTS_SALU"),
             "lds_bank_conflict_share": sq["SQ_LDS_BANK_CONFLICT"] / max(sq["SQ_LDS_IDX_ACTIVE"], 1.0),
             "assumed_clock_GHz": clock_ghz,
-            "note": "second bound: time the kernel's own vector instructions / LDS cycles need at peak clock"}
+            "note": "second bound: time the kernel's own vector / scalar instructions / LDS cycles need at peak clock"}
 
 
 def kernel_name(launch):
@@ -261,6 +265,7 @@ def measure_workload(ctx, A, workload_key, steps, warmup, opts=()):
                 roofline["issue_bound"] = ib
                 bounds["lds_array"] = min(ib["lds_frac_of_kernel_time"], 1.0)
                 bounds["valu_issue"] = min(ib["valu_frac_of_kernel_time"], 1.0)
+                bounds["salu_issue"] = min(ib["salu_frac_of_kernel_time"], 1.0)
         tight = max(bounds, key=bounds.get)
         roofline["bounds"] = {"frac_of_each": bounds, "tightest": tight, "frac_of_tightest": bounds[tight],
                               "note": "each entry = (time that bound alone would need) / kernel time, all <= 1; the LDS "

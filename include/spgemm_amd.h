@@ -120,6 +120,9 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   sym_rpw, grp_rpw                                1..64 (default 8): rows / row groups a wavefront of those two
  *                                                   kernels takes one after the other, the next one's
  *                                                   description in flight (1: one per wavefront)
+ *   rpw_fill                                        0..1024 (default 16): ... but no more than leave this many
+ *                                                   wavefronts of work per wavefront slot of the device
+ *                                                   (0: no such limit, small inputs take several too)
  *   short_packed                                    1: the numeric one reads the rows of B as 16-byte
  *                                                   {column, value} records padded to 128-byte lines
  *                                                   (built once per B handle, at most 7 records of

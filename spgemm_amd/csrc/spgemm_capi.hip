@@ -128,7 +128,7 @@ struct spgemm_ctx {
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
   uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
-  uint32_t rpw_fill = 16;        // ... but no more than leave this many wavefronts of work per wavefront slot of the device
+  uint32_t rpw_fill = 16;        // ... but no more than leave this many wavefronts of work per wavefront slot of the device (0: no such limit)
   uint32_t grp_rpw = 8;          // most groups one wavefront of the run kernel takes one after the other (<= 64)
   uint32_t sym_rpw = 8;          // the same for the symbolic window kernel of a B with runs (1: one row per wavefront, the plain kernel)
   int cu_count = 256;
@@ -810,7 +810,7 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "sym_rpw must be 1..64");
     ctx->sym_rpw = (uint32_t)value;
   } else if (n == "rpw_fill") {
-    if (value < 1 || value > 1024) return fail(SPGEMM_ERR_INVALID, "rpw_fill must be 1..1024");
+    if (value < 0 || value > 1024) return fail(SPGEMM_ERR_INVALID, "rpw_fill must be 0..1024");
     ctx->rpw_fill = (uint32_t)value;
   } else if (n == "grp_rpw") {
     if (value < 1 || value > 64) return fail(SPGEMM_ERR_INVALID, "grp_rpw must be 1..64");
@@ -1307,7 +1307,7 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       else if (walk_tail(ctx, B)) sym_kern = k_sym_window<false, true>;
       if (!flat && same_bits && ctx->sym_rpw > 1) {
         // B has runs of rows with one column list: the kernel whose wavefronts take several rows, the next one's description in flight
-        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->sym_rpw, cnt / ((uint64_t)ctx->cu_count * 32 * ctx->rpw_fill)));
+        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->sym_rpw, ctx->rpw_fill ? cnt / ((uint64_t)ctx->cu_count * 32 * ctx->rpw_fill) : cnt));
         hipLaunchKernelGGL(k_sym_window_runs, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream,
                            rows_bin, cnt, cA, cB, rm, words, same_bits, wpb, rpw);
       } else
@@ -1542,7 +1542,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
 #undef SG_RUN_ROW
         const run_kernel_t kern = tier ? wide[compact ? 1 : 0][gsel][rsel] : narrow[cap <= 128 ? 0 : 1][compact ? 1 : 0][gsel][rsel];
         // groups a wavefront takes one after the other: as many as leave 16 wavefronts of work per slot of the device
-        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->grp_rpw, cnt / ((uint64_t)ctx->cu_count * 32 * ctx->rpw_fill)));
+        const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->grp_rpw, ctx->rpw_fill ? cnt / ((uint64_t)ctx->cu_count * 32 * ctx->rpw_fill) : cnt));
         hipLaunchKernelGGL(kern, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream, rows_bin, cnt, cA, cB,
                            rowinfo_of(B).same, rm, no, words, cap, wpb, rpw);
       } else {

@@ -285,6 +285,18 @@ def test_row_groups_identical_patterns(ctx, dofs):
     finally:
         ctx.set_option("sym_rpw", 8)
         ctx.set_option("grp_rpw", 8)
+    # several per wavefront although the input is small (what a full-size matrix gets): 8, and 3 (a last
+    # wavefront with fewer)
+    ctx.set_option("rpw_fill", 0)
+    try:
+        check(ctx, A, A)
+        ctx.set_option("sym_rpw", 3)
+        ctx.set_option("grp_rpw", 3)
+        check(ctx, A, A)
+    finally:
+        ctx.set_option("sym_rpw", 8)
+        ctx.set_option("grp_rpw", 8)
+        ctx.set_option("rpw_fill", 16)
 
 
 def test_row_groups_with_cancellation_and_order(ctx):
