@@ -186,25 +186,27 @@ def cpu_baseline(A, target_seconds=10.0):
                                           f"fill pass with a dense accumulator per thread"}}
 
 
-def measure_workload(ctx, A, workload_key, steps, warmup, opts=()):
+def measure_workload(ctx, A, workload_key, steps, warmup, opts=(), alias_b=False):
     """Times `steps` multiplies C = A * A on the context (after `warmup` untimed ones, A resident in
-    HBM) and returns (ms per step, stats, launches with their mean durations, roofline of the
+    HBM; B is a second copy of the matrix in HBM, as the reference reads its two operands apart, unless
+    alias_b) and returns (ms per step, stats, launches with their mean durations, roofline of the
     dominant numeric launch, whole-multiply figures)."""
     import torch
     dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
+    dB = dA if alias_b else ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
     ctx.set_option("profile_launches", 1)
     for o in opts:
         opt_name, opt_value = o.split("=")
         ctx.set_option(opt_name, int(opt_value))
     for _ in range(warmup):
-        ctx.multiply(dA, dA).free()
+        ctx.multiply(dA, dB).free()
     ctx.synchronize()
     torch.cuda.synchronize()
     per_launch_ms = None
     phase_ms = {}
     t0 = time.perf_counter()
     for _ in range(steps):
-        C = ctx.multiply(dA, dA)
+        C = ctx.multiply(dA, dB)
         C.free()
         st = ctx.stats()
         ms = ctx.launch_ms()
@@ -220,10 +222,12 @@ def measure_workload(ctx, A, workload_key, steps, warmup, opts=()):
 
     # one untimed multiply that also sums the rows of every launch (bytes per launch)
     ctx.set_option("profile_launches", 2)
-    ctx.multiply(dA, dA).free()
+    ctx.multiply(dA, dB).free()
     launches = ctx.launches()
     st = ctx.stats()
     ctx.set_option("profile_launches", 0)
+    if dB is not dA:
+        dB.free()
     dA.free()
     for l, ms in zip(launches, per_launch_ms):
         l["ms"] = float(ms)
@@ -289,7 +293,7 @@ def run_single(args):
         raise SystemExit("bench.py needs a HIP device")
     A, name = make_workload(args)
     ctx = capi.Context(0)
-    ms_per_step, st, launches, roofline, whole = measure_workload(ctx, A, args.workload, args.steps, args.warmup, args.opt)
+    ms_per_step, st, launches, roofline, whole = measure_workload(ctx, A, args.workload, args.steps, args.warmup, args.opt, args.alias_b)
     gflops = 2.0 * st["nprod"] / (ms_per_step * 1e-3) / 1e9
     out = {
         "metric": "SpGEMM GFLOP/s (useful flops, 2*nprod/t) C=A*A fp64",
@@ -298,6 +302,7 @@ def run_single(args):
         "dtype": "f64", "data": "synthetic" if args.workload != "mtx" else "file",
         "config": {"workload": name, "rows": A.rows, "nnz_a": A.nnz, "nprod": st["nprod"], "nnz_c": st["nnz_c"],
                    "impl": "baseline", "parallelism": "1 GPU",
+                   "operands": "one device matrix as A and B" if args.alias_b else "A and B: two copies of the matrix in HBM",
                    "stand_in": "synthetic matrix of the named SuiteSparse matrix's order and row length; the real file "
                                "(not fetchable here) runs through --workload mtx" if args.workload in ("shell", "diel") else None},
         "roofline": roofline,
@@ -317,10 +322,11 @@ def run_single(args):
                                  ("diel", hostcsr.diel_like, "dielFilterV3real-like synthetic 3-D grid (n=1104192, ~81 nnz/row), C=A*A"),
                                  ("er", lambda: hostcsr.erdos_renyi(1 << 22, 16, seed=42), "Erdos-Renyi n=4194304, 16 draws/row, C=A*A")):
             M = make()
-            ms2, st2, l2, roof2, whole2 = measure_workload(ctx, M, key, k, 1, args.opt)
+            ms2, st2, l2, roof2, whole2 = measure_workload(ctx, M, key, k, 1, args.opt, args.alias_b)
             out["also"].append({
                 "config": {"workload": label, "rows": M.rows, "nnz_a": M.nnz, "nprod": st2["nprod"], "nnz_c": st2["nnz_c"],
                            "impl": "baseline", "parallelism": "1 GPU",
+                           "operands": "one device matrix as A and B" if args.alias_b else "A and B: two copies of the matrix in HBM",
                            "stand_in": "synthetic matrix of the named SuiteSparse matrix's order and row length" if key == "diel" else None},
                 "steps": k, "warmup": 1, "ms_per_step": ms2, "value": 2.0 * st2["nprod"] / (ms2 * 1e-3) / 1e9, "unit": "GFLOP/s",
                 "roofline": roof2, "whole_multiply": whole2,
@@ -354,6 +360,8 @@ def main():
                     help="default run (shell) only: leave out the blocks of the other workloads (R-MAT scale 22, 3-D grid, Erdos-Renyi)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option (spgemm_set_option), e.g. --opt row_groups=0")
+    ap.add_argument("--alias-b", action="store_true",
+                    help="pass one device matrix as both operands instead of two copies of it (its B reads then warm the caches for A)")
     ap.add_argument("--dist", action="store_true",
                     help="use the distributed operator even at N = 1 (rehearsal of the N > 1 path)")
     args = ap.parse_args()

@@ -306,7 +306,7 @@ constexpr bool GRP_RUN_ALDS = SG_GRP_ALDS != 0;
 // the next B row behind the first use of this one's, so that they land during its additions, lost
 // on both (scalar loads return in any order: every wait is for all that are out).
 #ifndef SG_GRP_ASCALAR
-#define SG_GRP_ASCALAR 1
+#define SG_GRP_ASCALAR 2
 #endif
 __host__ __device__ inline size_t grp_run_region(bool compact, uint32_t words, uint32_t cap, uint32_t gmax, bool wide) {
   return grp_region(compact, words, cap, gmax, 0) + (GRP_RUN_ALDS ? (size_t)gmax * (wide ? 128u : 64u) * 8u : 0u);
@@ -365,7 +365,8 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
 #pragma unroll
     for (uint32_t u = 0; u < TCN; ++u) tc[u] = tin[min(64u * u + lane, n - 1u)];
   };
-  RowRuns<WIDE> cur, nxt;
+  using Runs = RowRuns<WIDE, WIDE>; // (the narrow groups: units enumerated on the scalar unit)
+  Runs cur, nxt;
   auto len_of = [&](uint32_t g) { return (rl32(st_pack, g) >> 8) & 0xFFu; };
   cur.issue_a(A, readlane64(st_a0, 0), max(len_of(0), 1u), lane);
   {
@@ -388,10 +389,19 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
     const uint64_t a0 = readlane64(st_a0, g), coff = readlane64(st_coff, g);
     const uint32_t len_a = (pack >> 8) & 0xFFu;
     cur.len_a = len_a; // (a row without entries cannot be here; the loads above assumed one entry at least)
+    // Where the A values come through the scalar unit, its loads sit on the path of every unit (a row's
+    // values, a wait, the row's additions): the values must not come from HBM then.  One vector load
+    // touches every 128-byte line of the group's values (its rows lie back to back: 64 lines at most,
+    // one per lane) while the group is set up; its result is only waited for, after the units.
+    uint32_t a_touch = 0;
+    if constexpr (SG_GRP_ASCALAR == 1 || (SG_GRP_ASCALAR == 2 && WIDE)) {
+      const uint32_t dwords = cnt * len_a * 2u; // (>= 2)
+      a_touch = reinterpret_cast<const uint32_t *>(A.val + a0)[min(lane * 32u, dwords - 1u)];
+    }
     cur.template finish<RMAX>(lane);
     // the next group's description: bounds of its B rows now, column indices of the group after it
     nxt.issue_b(B, same_bits);
-    RowRuns<WIDE> aft;
+    Runs aft;
     aft.issue_a(A, readlane64(st_a0, g2), max(len_of(g2), 1u), lane);
     GR_STAMP(1) // waited for this group's description
     const uint32_t ntop = (nw + 31u) >> 5;
@@ -423,10 +433,12 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
     RunPipe<RMAX, true, GRP_RUN_SLOTS, WIDE> pipe;
     pipe.begin(B, cur, lane);
     lds_fence();
+    // (a row's base on the scalar unit, the position as a 32-bit lane offset: no 64-bit address per lane and row)
+    typedef uint32_t __attribute__((address_space(1))) *global_u32_ptr;
     grp_rank_build<COMPACT, TCN>(tc, n, base, lane, top32, cw32, [&](uint32_t p, uint32_t c) {
 #pragma unroll
       for (uint32_t j = 0; j < gmaxc; ++j)
-        if (j < cnt) o.c_col[coff + (uint64_t)j * n + p] = c;
+        if (j < cnt) ((global_u32_ptr)(uintptr_t)(o.c_col + coff + (uint64_t)j * n))[p & 0xFFFFu] = c;
     });
     auto compact_word = [&](uint32_t wi) {
       if constexpr (!COMPACT) return wi;
@@ -490,6 +502,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
       }
     });
     lds_fence();
+    asm volatile("" ::"v"(a_touch)); // (keeps the load above)
     GR_STAMP(3) // the units
 #pragma unroll
     for (uint32_t j = 0; j < gmaxc; ++j) {

@@ -240,7 +240,11 @@ template <int NV> struct RunVec {
   bool ok;          // ... if it holds one
   double bv[NV];    // the column's value in the run's rows (rows past the run's end repeat the last one); pattern walks: unused
 };
-template <bool WIDE> struct RowRuns {
+// TABLE: the units are laid out by the vector unit (below); else they are enumerated on the scalar unit,
+// one at a time (the kernels of the narrow groups: their walk is short, and the tables' registers
+// cost them a fifth of their wavefronts per CU)
+template <bool WIDE, bool TABLE = true> struct RowRuns {
+  static constexpr bool table = TABLE;
   // per lane: entry t (lo) and 64 + t (hi, WIDE only)
   uint64_t p0_lo, p0_hi;
   uint32_t len_lo, len_hi;
@@ -254,6 +258,10 @@ template <bool WIDE> struct RowRuns {
   uint64_t u_p0;                // per lane (unit of the table): start of the first of its B rows
   uint32_t u_L, u_meta;         // entries per row; first entry | rows << 8 | chunk << 16
   uint32_t nu, ui;              // wave-uniform: units in the table, next one to hand out
+  // !TABLE: the iterator on the scalar unit
+  uint32_t t, run_end, rl, L, chunk;
+  uint64_t p0;
+  bool done;
 
   // The description is loaded in two dependent steps, which a kernel that walks several rows one
   // after the other issues a row (and two rows) ahead: issue_a() loads the row's column indices k,
@@ -299,6 +307,11 @@ template <bool WIDE> struct RowRuns {
       if (lane == 0) kp_hi = k63;
       const bool cont_hi = 64u + lane < len && ((bits_hi >> (k_hi & 31u)) & 1u) && k_hi == kp_hi + 1u;
       start_hi = __ballot(64u + lane < len && !cont_hi);
+    }
+    if constexpr (!TABLE) {
+      t = 0; run_end = 0; rl = 0; L = 0; chunk = 0; p0 = 0;
+      done = len == 0;
+      return;
     }
     rs_lo = start_lo;
     rs_hi = start_hi;
@@ -376,6 +389,7 @@ template <bool WIDE> struct RowRuns {
                                        uint32_t len, uint32_t lane) {
     if (len == 0) { // wave-uniform
       len_a = 0; start_lo = start_hi = 0; rs_lo = rs_hi = 0; ph = 0; ph_tot = 0; ph_done = 0; nu = 0; ui = 0;
+      done = true; rl = 0; L = 0; chunk = 0; t = 0; run_end = 0; p0 = 0;
       p0_lo = p0_hi = 0; len_lo = len_hi = 0;
       return;
     }
@@ -384,10 +398,46 @@ template <bool WIDE> struct RowRuns {
     finish<RMAX>(lane);
   }
   // more units after those of the table
-  __device__ __forceinline__ bool more() const { return ph_done < ph_tot || (WIDE && ph == 0u && rs_hi != 0ull); }
-  // the next unit of the table (RMAX: as given to finish()); the caller refills an empty table
+  __device__ __forceinline__ bool more() const { return TABLE && (ph_done < ph_tot || (WIDE && ph == 0u && rs_hi != 0ull)); }
+  // !TABLE: first entry >= from that begins a run (len_a when there is none)
+  __device__ __forceinline__ uint32_t next_start(uint32_t from) const {
+    if (from < 64u) {
+      const uint64_t m = start_lo >> from;
+      if (m) return from + (uint32_t)__builtin_ctzll(m);
+      from = 64u;
+    }
+    if constexpr (WIDE) {
+      if (from < 128u) {
+        const uint64_t m = start_hi >> (from - 64u);
+        if (m) return from + (uint32_t)__builtin_ctzll(m);
+      }
+    }
+    return len_a;
+  }
+  // the next unit (RMAX: as given to finish()).  TABLE: of the table; the caller refills an empty one
   template <int RMAX> __device__ __forceinline__ RunInfo next() {
     RunInfo r{0, 0, 1, 0, 0, false};
+    if constexpr (!TABLE) {
+      if (done) return r;
+      if (rl != 0 && (chunk + 1u) * 64u < L) { // more columns of the same rows
+        ++chunk;
+      } else {
+        t += rl; // (0 before the first unit)
+        if (t >= len_a) { done = true; return r; }
+        if (t >= run_end) run_end = next_start(t + 1u);
+        rl = min(run_end - t, (uint32_t)RMAX);
+        chunk = 0;
+        if constexpr (WIDE) {
+          if (t < 64u) { p0 = readlane64(p0_lo, t); L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t); }
+          else { p0 = readlane64(p0_hi, t - 64u); L = (uint32_t)__builtin_amdgcn_readlane((int)len_hi, (int)(t - 64u)); }
+        } else {
+          p0 = readlane64(p0_lo, t);
+          L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)t);
+        }
+      }
+      r.p0 = p0; r.L = L; r.rl = rl; r.t0 = t; r.chunk = chunk; r.valid = true;
+      return r;
+    }
     if (ui >= nu) return r; // wave-uniform
     const uint32_t i = ui++;
     const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)u_meta, (int)i);
@@ -434,14 +484,25 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
 template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
   RunInfo info[SLOTS];
   RunVec<WITH_VAL ? RMAX : 1> vec[SLOTS];
-  __device__ __forceinline__ void begin(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane) {
+  template <class RR> __device__ __forceinline__ void begin(const Csr &B, RR &rr, uint32_t lane) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       info[s] = rr.template next<RMAX>();
       run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
     }
   }
-  template <class F> __device__ __forceinline__ void run(const Csr &B, RowRuns<WIDE> &rr, uint32_t lane, F f) {
+  template <class RR, class F> __device__ __forceinline__ void run(const Csr &B, RR &rr, uint32_t lane, F f) {
+    if constexpr (!RR::table) { // units enumerated one by one: no table to drain at
+      for (;;) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          if (!info[s].valid) return; // the units come in order: the first empty slot ends the walk
+          f(info[s], vec[s]);
+          info[s] = rr.template next<RMAX>();
+          run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+        }
+      }
+    }
     for (;;) {
       // the units of one table; the pipeline drains at its end (once per 64 units)
       for (bool open = true; open;) {
