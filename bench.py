@@ -322,6 +322,8 @@ def run_single(args):
                                  ("diel", hostcsr.diel_like, "dielFilterV3real-like synthetic 3-D grid (n=1104192, ~81 nnz/row), C=A*A"),
                                  ("er", lambda: hostcsr.erdos_renyi(1 << 22, 16, seed=42), "Erdos-Renyi n=4194304, 16 draws/row, C=A*A")):
             M = make()
+            ctx.close()  # (a context of its own per workload: the pooled buffers of the last one, 100 GB after R-MAT, go back)
+            ctx = capi.Context(0)
             ms2, st2, l2, roof2, whole2 = measure_workload(ctx, M, key, k, 1, args.opt, args.alias_b)
             out["also"].append({
                 "config": {"workload": label, "rows": M.rows, "nnz_a": M.nnz, "nprod": st2["nprod"], "nnz_c": st2["nnz_c"],

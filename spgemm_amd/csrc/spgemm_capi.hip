@@ -182,7 +182,7 @@ struct spgemm_ctx {
 
 static constexpr size_t PINNED_BYTES = 8192;
 static void release_mat(spgemm_ctx *ctx, spgemm_mat *m);
-static constexpr size_t POOL_LIMIT_BLOCKS = 16;
+static constexpr size_t POOL_LIMIT_BLOCKS = 32;
 
 // ---- scratch of the allocation-free entry point -----------------------------------------------------
 // spgemm_assemble_row_ptr_noalloc keeps its row lengths and scan partials here instead of in the
@@ -262,13 +262,12 @@ static int pool_alloc(spgemm_ctx *ctx, size_t bytes, void **out, size_t *got) {
 static void pool_release(spgemm_ctx *ctx, void *p, size_t bytes) {
   if (!p) return;
   if (ctx->pool.size() >= POOL_LIMIT_BLOCKS) {
-    // drop the smallest block
-    size_t s = 0;
-    for (size_t i = 1; i < ctx->pool.size(); ++i)
-      if (ctx->pool[i].bytes < ctx->pool[s].bytes) s = i;
-    (void)hipFree(ctx->pool[s].p);
-    ctx->pool_bytes -= ctx->pool[s].bytes;
-    ctx->pool.erase(ctx->pool.begin() + s);
+    // drop the block that has waited longest (blocks are appended as they come back and taken from wherever
+    // they fit): after a change of workload the blocks of the old one go, not the small ones of the new
+    // one, which would then be allocated and freed in every multiply
+    (void)hipFree(ctx->pool[0].p);
+    ctx->pool_bytes -= ctx->pool[0].bytes;
+    ctx->pool.erase(ctx->pool.begin());
   }
   ctx->pool.push_back({p, bytes});
   ctx->pool_bytes += bytes;
