@@ -299,6 +299,43 @@ def test_row_groups_identical_patterns(ctx, dofs):
         ctx.set_option("rpw_fill", 16)
 
 
+def _node_blocks(P, dofs, rng):
+    """Every entry of the node matrix P becomes a dofs x dofs block: runs of `dofs` rows with one column list."""
+    rid, cid = P.row_ids(), P.col_idx.astype(np.int64)
+    r = (rid[:, None, None] * dofs + np.arange(dofs)[None, :, None]).repeat(dofs, axis=2)
+    c = (cid[:, None, None] * dofs + np.arange(dofs)[None, None, :]).repeat(dofs, axis=1)
+    v = rng.random(r.size) * 2 - 1
+    return hostcsr.HostCsr.from_coo(P.rows * dofs, P.cols * dofs, r.ravel(), c.ravel(), v)
+
+
+@pytest.mark.parametrize("dofs,a_nodes,b_nodes", [(3, 40, 70), (2, 60, 100), (5, 24, 60)])
+def test_row_runs_more_than_64_units_per_half(ctx, dofs, a_nodes, b_nodes):
+    # A rows of up to 128 entries that select runs of long B rows (several chunks of 64 columns each):
+    # more than 64 units in the first and in the second half of the A row, so the unit tables of the run
+    # walk are refilled, in the symbolic pass and in the numeric pass of the wide groups
+    rng = np.random.default_rng(100 * dofs + a_nodes)
+    nodes = min(140, 500 // dofs)  # (at most 512 outputs per row: the rows stay grouped)
+
+    def node_matrix(per_row):
+        r = np.repeat(np.arange(nodes), per_row)
+        c = np.concatenate([np.sort(rng.choice(nodes, per_row, replace=False)) for _ in range(nodes)])
+        return hostcsr.HostCsr.from_coo(nodes, nodes, r, c, np.ones(len(r)))
+
+    A = _node_blocks(node_matrix(a_nodes), dofs, rng)
+    B = _node_blocks(node_matrix(b_nodes), dofs, rng)
+    assert 64 < A.nnz // A.rows <= 128 and B.nnz // B.rows > 128
+    for fill in (16, 0):
+        ctx.set_option("rpw_fill", fill)
+        ctx.set_option("profile_launches", 1)
+        try:
+            check(ctx, A, B)
+            # (the case must reach the kernels it is written for)
+            assert any(l["phase"] == "numeric" and l["path"] == "window_group_runs" for l in ctx.launches())
+        finally:
+            ctx.set_option("rpw_fill", 16)
+            ctx.set_option("profile_launches", 0)
+
+
 def test_row_groups_with_cancellation_and_order(ctx):
     # identical column lists but stored in a different order must NOT be grouped (the k order
     # differs); identical rows whose values cancel exactly are dropped per row
