@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# RCCL and device-tensor sharing between the ranks of a node need the dmabuf IPC mode on this driver
+# (the boxes export it already; a launcher that scrubs the environment must not lose it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
