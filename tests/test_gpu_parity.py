@@ -336,6 +336,41 @@ def test_row_runs_more_than_64_units_per_half(ctx, dofs, a_nodes, b_nodes):
             ctx.set_option("profile_launches", 0)
 
 
+def test_row_runs_half_boundary_and_empty_b_rows(ctx):
+    # A rows of 1 .. 128 entries that select CONSECUTIVE rows of a B made of blocks of identical rows
+    # (some blocks empty): runs that cross the 64th entry, runs cut by the row's end, empty B rows
+    # inside a run, rows of exactly 64 / 65 / 128 entries; every A row twice, so that the group
+    # kernels take them too
+    rng = np.random.default_rng(77)
+    nb, cols, dof = 480, 300, 5
+    br, bc = [], []
+    for blk in range(nb // dof):
+        L = 0 if blk % 7 == 3 else int(rng.integers(3, 91))
+        cl = np.sort(rng.choice(cols, L, replace=False))
+        for i in range(dof):
+            br.append(np.full(L, blk * dof + i))
+            bc.append(cl)
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    B = hostcsr.HostCsr.from_coo(nb, cols, br, bc, rng.random(len(br)) * 2 - 1)
+    ar, ac = [], []
+    row = 0
+    for ln in (1, 2, 5, 6, 59, 63, 64, 65, 66, 69, 100, 127, 128):
+        for start in (0, 3, int(rng.integers(0, nb - 128))):
+            ks = np.arange(start, start + ln)
+            for _ in range(2):
+                ar.append(np.full(ln, row))
+                ac.append(ks)
+                row += 1
+    ar, ac = np.concatenate(ar), np.concatenate(ac)
+    A = hostcsr.HostCsr.from_coo(row, nb, ar, ac, rng.random(len(ar)) * 2 - 1)
+    for fill in (16, 0):
+        ctx.set_option("rpw_fill", fill)
+        try:
+            check(ctx, A, B)
+        finally:
+            ctx.set_option("rpw_fill", 16)
+
+
 def test_row_groups_with_cancellation_and_order(ctx):
     # identical column lists but stored in a different order must NOT be grouped (the k order
     # differs); identical rows whose values cancel exactly are dropped per row
