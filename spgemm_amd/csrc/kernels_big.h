@@ -378,16 +378,33 @@ __global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_e
           if (s_pre[e + sft] <= q) e += sft;
         return e;
       };
+      // The 64 products of a wavefront's step lie in a few neighbouring pieces.  Lane l keeps the prefix of
+      // entry 8 l; two ballots (prefixes <= the step's first and last product) bound the entries of the
+      // step, and where they span 8 or 16 the search takes 3 or 4 steps instead of 9.
+      static_assert(BIG_THREADS == 512, "one coarse prefix per lane: every 8th of 512 entries");
+      const uint32_t coarse = s_pre[lane * 8u];
       constexpr int NF = 8; // products of a thread whose loads are in flight together
       for (uint32_t q0 = 0; q0 < total; q0 += BIG_THREADS * NF) {
         uint32_t c[NF];
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
-          const uint32_t q = q0 + (uint32_t)u * BIG_THREADS + tid;
+          const uint32_t qw = q0 + (uint32_t)u * BIG_THREADS + wv * 64u; // (wave-uniform) the step's first product
+          const uint32_t q = qw + lane;
           c[u] = EMPTY_KEY;
-          if (q < total) {
-            const uint32_t e = entry_of(q);
-            c[u] = B.col[s_base[e] + (q - s_pre[e])];
+          if (qw < total) { // wave-uniform
+            const uint32_t n_lo = (uint32_t)__popcll(__ballot(coarse <= qw));
+            const uint32_t n_hi = (uint32_t)__popcll(__ballot(coarse <= min(qw + 63u, total - 1u)));
+            uint32_t e;
+            if (n_hi - n_lo <= 1u) { // the step's entries lie in [8 (n_lo - 1), 8 n_hi): 8 or 16 of them
+              e = (n_lo - 1u) * 8u;   // (the prefix of entry 0 is 0: n_lo >= 1)
+              if (n_hi != n_lo && s_pre[e + 8u] <= q) e += 8u;
+#pragma unroll
+              for (uint32_t sft = 4; sft > 0; sft >>= 1)
+                if (s_pre[e + sft] <= q) e += sft;
+            } else {
+              e = entry_of(q);
+            }
+            if (q < total) c[u] = B.col[s_base[e] + (q - s_pre[e])];
           }
         }
 #pragma unroll
