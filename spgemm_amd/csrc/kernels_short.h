@@ -16,24 +16,28 @@ __host__ __device__ constexpr uint32_t sh_scratch(bool numeric, uint32_t steps) 
 }
 
 // Monotone map of the columns of B onto [0, nnz(B)]: F(c) = number of entries of B in columns < c,
-// piecewise linear over CDF_BINS equal column ranges (cdf[b] = entries in the bins before b, exact
-// integers held as doubles).  A row's columns, drawn from B's rows, are spread evenly by F whatever
+// piecewise linear over CDF_BINS equal column ranges (cdf[b] = entries in the bins before b, rounded to
+// single precision: the map only has to be monotone - rounding is - and to tell a few hundred home
+// slots apart, and a row pays for six evaluations and a division of it, which cost a tenth of the
+// kernel's vector instructions in double precision).  A row's columns, drawn from B's rows, are spread evenly by F whatever
 // the popularity of B's columns (R-MAT hubs), which keeps the clusters of the sorted table short.
 constexpr uint32_t CDF_BINS = 2048;
 struct ColMap {
-  const double *__restrict__ cdf; // CDF_BINS + 1 entries
+  const float *__restrict__ cdf;  // CDF_BINS + 1 entries, then 1.0 if the entries of B are spread evenly over its columns (k_col_cdf)
   uint32_t shift;                 // bin of column c = c >> shift
-  double inv_width;               // 2^-shift
+  float inv_width;                // 2^-shift
   const uint4 *__restrict__ prec; // B rows as padded {column, 0, value} records (k_prec_fill), or null
   const uint32_t *__restrict__ pcol; // the columns of those records alone, at the same positions, or null
 };
 // value of the map at column c, given the prefix counts lo, hi at the two ends of c's bin
-__device__ __forceinline__ double colmap_interp(const ColMap &cm, uint32_t c, double lo, double hi) {
+__device__ __forceinline__ float colmap_interp(const ColMap &cm, uint32_t c, float lo, float hi) {
   const uint32_t b = c >> cm.shift;
-  const double frac = (double)(c - (b << cm.shift)) * cm.inv_width;
+  const float frac = (float)(c - (b << cm.shift)) * cm.inv_width;
   return lo + (hi - lo) * frac;
 }
-__device__ __forceinline__ double colmap_eval(const ColMap &cm, uint32_t c) {
+// lin (wave-uniform): the entries of B are spread evenly over its columns: the column itself is the map, no table read
+__device__ __forceinline__ float colmap_eval(const ColMap &cm, uint32_t c, bool lin) {
+  if (lin) return (float)c;
   const uint32_t b = c >> cm.shift;
   return colmap_interp(cm, c, cm.cdf[b], cm.cdf[b + 1]);
 }
@@ -104,7 +108,7 @@ template <bool NUMERIC, int STEPS> struct ShortSet {
   double bv[STEPS];
   uint32_t row, total, n, cmin, cmax;
   uint64_t off;
-  double f[4]; // column map around cmin and cmax (numeric)
+  float f[4]; // column map around cmin and cmax (numeric)
 };
 template <bool NUMERIC, int STEPS>
 __device__ __forceinline__ void short_expand(const Csr &B, const ColMap &cm, const ShortFetch &f, uint32_t lane,
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(256)
   const size_t region = (size_t)S * 4u + sh_scratch(false, STEPS);
   uint32_t *keys = reinterpret_cast<uint32_t *>(smem + w * region);
   unsigned char *scratch = smem + w * region + (size_t)S * 4u;
-  const ColMap none{nullptr, 0, 0.0, nullptr, pcol};
+  const ColMap none{nullptr, 0, 0.0f, nullptr, pcol};
   ShortFetch fa;
   ShortSet<false, STEPS> cur, nxt;
   short_fetch<false>(A, B, m, none, nullptr, rows, first, lane, fa);
@@ -293,6 +297,7 @@ __global__ void __launch_bounds__(256)
   auto col_of = [&](key_t e) { return (uint32_t)(e >> cshift); };
   auto q_of = [&](key_t e) { return K32 ? (uint32_t)e & (PM - 1u) : (uint32_t)e; };
   uint32_t nz = 0;
+  const bool lin = scalar_view(cm.cdf)[CDF_BINS + 1u] != 0.0f; // wave-uniform
   ShortFetch fa;
   ShortSet<true, STEPS> cur, nxt;
   const double *avs = reinterpret_cast<const double *>(scratch + 768 + 64 * STEPS);
@@ -312,14 +317,14 @@ __global__ void __launch_bounds__(256)
     }
     // the row's own column range stretched over the home slots
     // (the same expression as colmap_eval, so that a product in column cmin maps to exactly f_lo)
-    const double f_lo = colmap_interp(cm, cur.cmin, cur.f[0], cur.f[1]);
-    const double f_hi = colmap_interp(cm, cur.cmax, cur.f[2], cur.f[3]);
-    const double scale = (double)H / (f_hi - f_lo + 1.0);
+    const float f_lo = lin ? (float)cur.cmin : colmap_interp(cm, cur.cmin, cur.f[0], cur.f[1]);
+    const float f_hi = lin ? (float)cur.cmax : colmap_interp(cm, cur.cmax, cur.f[2], cur.f[3]);
+    const float scale = (float)H / (f_hi - f_lo + 1.0f);
     key_t x[STEPS];
     uint32_t h[STEPS];
-    double fc[STEPS];
+    float fc[STEPS];
 #pragma unroll
-    for (int u = 0; u < STEPS; ++u) fc[u] = cur.c[u] != EMPTY_KEY ? colmap_eval(cm, cur.c[u]) : 0.0;
+    for (int u = 0; u < STEPS; ++u) fc[u] = cur.c[u] != EMPTY_KEY ? colmap_eval(cm, cur.c[u], lin) : 0.0f;
     lds_fence();
 #pragma unroll
     for (int u = 0; u < STEPS; ++u) {
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(256)
         const uint32_t q = (uint32_t)u * 64u + lane;
         prodv[q] = __dmul_rn(avs[cur.t[u]], cur.bv[u]);
         x[u] = ((key_t)cur.c[u] << cshift) | q;
-        h[u] = min(H - 1u, (uint32_t)fmax(0.0, (fc[u] - f_lo) * scale)); // (never below zero: the map is monotone)
+        h[u] = min(H - 1u, (uint32_t)fmaxf(0.0f, (fc[u] - f_lo) * scale)); // (never below zero: the map is monotone)
       }
     }
     // the row's values and A entries are used up: the next row is expanded now (its B entries are in
@@ -434,16 +439,36 @@ __global__ void __launch_bounds__(256)
   for (uint32_t i = threadIdx.x; i < CDF_BINS; i += blockDim.x)
     if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
-// one workgroup of 1024 threads, two bins per thread; cdf[b] = entries in the bins before b
-__global__ void __launch_bounds__(1024) k_col_cdf(const uint32_t *__restrict__ hist, double *__restrict__ cdf) {
+// one workgroup of 1024 threads, two bins per thread; cdf[b] = entries in the bins before b.
+// cdf[CDF_BINS + 1] = 1 where the entries are spread evenly over the `used` column ranges that exist
+// (no prefix count further than 1/256 of the entries from the straight line): the kernel then takes
+// the column itself for the map and reads no table (Erdos-Renyi: a tenth of its numeric pass).
+__global__ void __launch_bounds__(1024) k_col_cdf(const uint32_t *__restrict__ hist, float *__restrict__ cdf, uint32_t used) {
   __shared__ uint64_t s_wave[16];
+  __shared__ unsigned long long s_dev;
   const uint32_t i = threadIdx.x;
+  if (i == 0) s_dev = 0ull;
   const uint64_t a = hist[2u * i], b = hist[2u * i + 1u];
   uint64_t tot;
-  const uint64_t ex = block_excl_scan64(a + b, s_wave, &tot);
-  cdf[2u * i] = (double)ex;
-  cdf[2u * i + 1u] = (double)(ex + a);
-  if (i == 0) cdf[CDF_BINS] = (double)tot;
+  const uint64_t ex = block_excl_scan64(a + b, s_wave, &tot); // (barriers inside: s_dev is set)
+  cdf[2u * i] = (float)ex;
+  cdf[2u * i + 1u] = (float)(ex + a);
+  unsigned long long dev = 0;
+#pragma unroll
+  for (uint32_t h = 0; h < 2u; ++h) {
+    const uint32_t bin = 2u * i + h;
+    if (bin <= used) {
+      const uint64_t have = h ? ex + a : ex;
+      const uint64_t line = (uint64_t)((unsigned __int128)tot * bin / max(used, 1u));
+      dev = max(dev, (unsigned long long)(have > line ? have - line : line - have));
+    }
+  }
+  if (dev) atomicMax(&s_dev, dev);
+  __syncthreads();
+  if (i == 0) {
+    cdf[CDF_BINS] = (float)tot;
+    cdf[CDF_BINS + 1u] = s_dev <= (tot >> 8) ? 1.0f : 0.0f;
+  }
 }
 
 } // namespace sg

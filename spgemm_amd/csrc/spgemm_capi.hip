@@ -57,7 +57,7 @@ struct spgemm_mat {
   int device = 0;
   uint32_t rowinfo_sh = 1;    // layout of d_rowinfo (RowInfo): 1 = halves side by side, 0 = in two arrays
   uint4 *d_rowinfo = nullptr; // {min col, max col, length} per row, built on first use as B
-  double *d_colcdf = nullptr; // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
+  float *d_colcdf = nullptr;  // CDF_BINS + 1 prefix counts of the entries per column range (+ the histogram behind them)
   uint32_t cdf_shift = 0;     // column range b holds the columns c with c >> cdf_shift == b
   size_t bytes_ptr = 0, bytes_col = 0, bytes_val = 0, bytes_rowinfo = 0, bytes_colcdf = 0;
   uint64_t *d_prow = nullptr; // scratch of the padded-record layout (row starts, scan partials, counts)
@@ -452,7 +452,7 @@ static int ensure_colcdf(spgemm_ctx *ctx, const spgemm_mat *B) {
   uint32_t shift = 0;
   while (B->cols && ((B->cols - 1) >> shift) >= CDF_BINS) ++shift;
   mb->cdf_shift = shift;
-  const size_t cdf_bytes = align_up((CDF_BINS + 1) * sizeof(double), 256);
+  const size_t cdf_bytes = align_up((CDF_BINS + 2) * sizeof(float), 256); // + the flag of an even spread
   TRY(pool_alloc(ctx, cdf_bytes + CDF_BINS * sizeof(uint32_t), (void **)&mb->d_colcdf, &mb->bytes_colcdf));
   uint32_t *hist = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mb->d_colcdf) + cdf_bytes);
   HIP_TRY(hipMemsetAsync(hist, 0, CDF_BINS * sizeof(uint32_t), ctx->stream));
@@ -460,7 +460,8 @@ static int ensure_colcdf(spgemm_ctx *ctx, const spgemm_mat *B) {
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(div_up_u64(B->nnz, 256 * 16), 2048);
     hipLaunchKernelGGL(k_col_hist, dim3(blocks), dim3(256), 0, ctx->stream, B->nnz, B->d_col, shift, hist);
   }
-  hipLaunchKernelGGL(k_col_cdf, dim3(1), dim3(1024), 0, ctx->stream, hist, mb->d_colcdf);
+  hipLaunchKernelGGL(k_col_cdf, dim3(1), dim3(1024), 0, ctx->stream, hist, mb->d_colcdf,
+                     B->cols ? (uint32_t)((B->cols - 1) >> shift) + 1u : 0u);
   HIP_TRY(hipGetLastError());
   return SPGEMM_OK;
 }
@@ -1563,7 +1564,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       const uint32_t wpb = pick_wpb(region);
       TRY(ensure_colcdf(ctx, B));
       if (pl.a_pk) TRY(ensure_prec(ctx, B));
-      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0 / (double)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr, nullptr};
+      ColMap cm{B->d_colcdf, B->cdf_shift, 1.0f / (float)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr, nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
       const uint32_t rpw = short_rows_per_wave(ctx, cnt);
       const bool four = num_short_steps(log2pm) == 4;
