@@ -55,15 +55,19 @@ struct __attribute__((packed, aligned(4))) Rec12 {
 // In the hash bins sub-bin 0 (key & 3 == 0) is theirs alone; the other rows use sub-bins 1..3.
 constexpr uint32_t SH_MAX_NPROD = 512, SH_MAX_ALEN = 64;
 
+// smallest l with 2^l >= x, at most 31 (every row of the analysis computes two of these and the class
+// below: a counting loop and a 64-bit division here were a third of that kernel's vector instructions)
 __host__ __device__ inline uint32_t ceil_log2_u32(uint32_t x) {
-  uint32_t l = 0;
-  while ((1u << l) < x && l < 31) ++l;
-  return l;
+  if (x <= 1u) return 0u;
+  const uint32_t l = 32u - (uint32_t)__builtin_clz(x - 1u);
+  return l < 31u ? l : 31u;
 }
 
+// class of the mean length of the row's B rows, ceil(nprod / len_a), against the three thresholds
+// (ceil(n / d) <= t is n <= t * d: no division)
 __host__ __device__ inline uint32_t gsel_of(uint64_t nprod, uint32_t len_a, const ClassParams &p) {
-  uint32_t avg = len_a ? (uint32_t)((nprod + len_a - 1) / len_a) : 0;
-  return avg <= p.g_thresh0 ? 0u : avg <= p.g_thresh1 ? 1u : avg <= p.g_thresh2 ? 2u : 3u;
+  return nprod <= (uint64_t)p.g_thresh0 * len_a ? 0u : nprod <= (uint64_t)p.g_thresh1 * len_a ? 1u
+         : nprod <= (uint64_t)p.g_thresh2 * len_a ? 2u : 3u;
 }
 
 __host__ __device__ inline uint32_t sym_key_of(uint64_t nprod, uint32_t span, uint32_t len_a,
