@@ -228,19 +228,50 @@ __global__ void __launch_bounds__(256)
       c[u] = cur.c[u];
       h[u] = c[u] != EMPTY_KEY ? hash_slot(c[u], log2s) : lane;
     }
-    for (;;) {
+    for (uint32_t round = 0;; ++round) {
       uint32_t old[STEPS];
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, c[u]);
       bool open = false;
+      uint32_t left = 0; // (wave-uniform) products whose chain goes on
+      uint64_t bal[STEPS];
 #pragma unroll
       for (int u = 0; u < STEPS; ++u) {
         mine += (old[u] == EMPTY_KEY && c[u] != EMPTY_KEY) ? 1u : 0u;
         c[u] = (old[u] == EMPTY_KEY || old[u] == c[u]) ? EMPTY_KEY : c[u];
         h[u] = c[u] != EMPTY_KEY ? (h[u] + 1u) & mask : lane; // the table is at most half full: an empty slot comes
         open |= c[u] != EMPTY_KEY;
+        bal[u] = __ballot(c[u] != EMPTY_KEY);
+        left += (uint32_t)__popcll(bal[u]);
       }
-      if (!__any(open)) break;
+      if (left == 0u) break;
+      // Most products find their slot at once; the few that go on (a quarter of the table is in use) are
+      // handed one to a lane, through the walk scratch, which is free now: the rounds that follow cost one
+      // compare-and-swap per round instead of one per step of the row.
+      if (round == 0u && left <= 64u) {
+        uint32_t *lst = reinterpret_cast<uint32_t *>(scratch); // {column, slot} pairs
+        uint32_t before = 0;
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+          if (c[u] != EMPTY_KEY) {
+            const uint32_t at = before + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
+            lst[2u * at] = c[u];
+            lst[2u * at + 1u] = h[u];
+          }
+          before += (uint32_t)__popcll(bal[u]);
+        }
+        lds_fence();
+        uint32_t cc = EMPTY_KEY, hh = lane;
+        if (lane < left) { cc = lst[2u * lane]; hh = lst[2u * lane + 1u]; }
+        for (;;) {
+          const uint32_t o1 = atomicCAS(&keys[hh], EMPTY_KEY, cc);
+          mine += (o1 == EMPTY_KEY && cc != EMPTY_KEY) ? 1u : 0u;
+          cc = (o1 == EMPTY_KEY || o1 == cc) ? EMPTY_KEY : cc;
+          hh = cc != EMPTY_KEY ? (hh + 1u) & mask : lane;
+          if (!__any(cc != EMPTY_KEY)) break;
+        }
+        break;
+      }
     }
     const uint32_t n = group_sum<64>(mine);
     if (lane == 0) {
@@ -351,16 +382,47 @@ __global__ void __launch_bounds__(256)
         key_t old[STEPS];
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) old[u] = atomicMin(&tab[h[u]], x[u]);
-        bool open = false;
+        uint32_t left = 0; // (wave-uniform) chains that go on
+        uint64_t bal[STEPS];
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
           x[u] = old[u] > x[u] ? old[u] : x[u]; // the larger one is carried on; "empty" ends the chain
           const bool last_slot = h[u] + 1u >= T; // cannot happen to a chain: at most `total` entries past the last home slot
           x[u] = last_slot ? EMPTY64 : x[u];
           h[u] = x[u] != EMPTY64 ? h[u] + 1u : lane;
-          open |= x[u] != EMPTY64;
+          bal[u] = __ballot(x[u] != EMPTY64);
+          left += (uint32_t)__popcll(bal[u]);
         }
-        if (!__any(open)) break;
+        if (left == 0u) break;
+        // once 64 chains or fewer go on, each gets a lane of its own (through the part of the walk scratch
+        // that the next row's expansion has left free: its A values, kept behind it, stay): a round then
+        // costs one atomic instead of one per step of the row
+        if (left <= 64u) {
+          key_t *lx = reinterpret_cast<key_t *>(scratch);
+          uint32_t *lh = reinterpret_cast<uint32_t *>(scratch + 512);
+          uint32_t before = 0;
+#pragma unroll
+          for (int u = 0; u < STEPS; ++u) {
+            if (x[u] != EMPTY64) {
+              const uint32_t at = before + (uint32_t)__popcll(bal[u] & ((1ull << lane) - 1ull));
+              lx[at] = x[u];
+              lh[at] = h[u];
+            }
+            before += (uint32_t)__popcll(bal[u]);
+          }
+          lds_fence();
+          key_t xx = EMPTY64;
+          uint32_t hh = lane;
+          if (lane < left) { xx = lx[lane]; hh = lh[lane]; }
+          for (;;) {
+            const key_t o1 = atomicMin(&tab[hh], xx);
+            xx = o1 > xx ? o1 : xx;
+            xx = hh + 1u >= T ? EMPTY64 : xx;
+            hh = xx != EMPTY64 ? hh + 1u : lane;
+            if (!__any(xx != EMPTY64)) break;
+          }
+          break;
+        }
       }
     lds_fence();
     // 2. the occupied slots are moved to the front of the table, in slot order (16 bytes of slots per
