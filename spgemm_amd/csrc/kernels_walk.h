@@ -311,7 +311,6 @@ template <bool WIDE, bool TABLE = true> struct RowRuns {
     if constexpr (!TABLE) {
       t = 0; run_end = 0; rl = 0; L = 0; chunk = 0; p0 = 0;
       done = len == 0;
-      return;
     }
     rs_lo = start_lo;
     rs_hi = start_hi;
@@ -327,7 +326,8 @@ template <bool WIDE, bool TABLE = true> struct RowRuns {
       }
     }
     ph = 0; ph_tot = 0; ph_done = 0; nu = 0; ui = 0;
-    if (len) refill(lane);
+    if constexpr (TABLE)
+      if (len) refill(lane);
   }
   // prefix sums of the chunk counts of half ph's entries that begin a unit's rows (base: units before the
   // entry's; rows: rows of its unit).  Recomputed by every refill: a second one is rare (more than 64
@@ -417,6 +417,25 @@ template <bool WIDE, bool TABLE = true> struct RowRuns {
   // the next unit (RMAX: as given to finish()).  TABLE: of the table; the caller refills an empty one
   template <int RMAX> __device__ __forceinline__ RunInfo next() {
     RunInfo r{0, 0, 1, 0, 0, false};
+    if constexpr (!TABLE && !WIDE) {
+      // rows of up to 64 entries: the entries that begin a unit's rows are the bits of rs_lo; the next
+      // unit's entry is the lowest one, its rows end at the one after it
+      if (done) return r;
+      if (rl != 0 && (chunk + 1u) * 64u < L) { // more columns of the same rows
+        ++chunk;
+      } else {
+        if (rs_lo == 0ull) { done = true; return r; }
+        const uint32_t tt = (uint32_t)__builtin_ctzll(rs_lo);
+        rs_lo &= rs_lo - 1ull;
+        t = tt;
+        rl = (rs_lo ? (uint32_t)__builtin_ctzll(rs_lo) : len_a) - tt;
+        chunk = 0;
+        p0 = readlane64(p0_lo, tt);
+        L = (uint32_t)__builtin_amdgcn_readlane((int)len_lo, (int)tt);
+      }
+      r.p0 = p0; r.L = L; r.rl = rl; r.t0 = t; r.chunk = chunk; r.valid = true;
+      return r;
+    }
     if constexpr (!TABLE) {
       if (done) return r;
       if (rl != 0 && (chunk + 1u) * 64u < L) { // more columns of the same rows
