@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_e
       uint64_t total64;
       const uint32_t excl = (uint32_t)block_excl_scan64(plen, s_wave, &total64); // (two barriers inside: the batch before is done with s_pre / s_base)
       s_pre[tid] = excl;
-      s_base[tid] = base;
+      s_base[tid] = base - excl; // (product q of the batch sits at s_base[entry] + q: one read and no subtraction per product)
       if (tid == 0) s_pre[BIG_THREADS] = (uint32_t)total64;
       __syncthreads();
       BIG2_STAMP(0);
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_e
             } else {
               e = entry_of(q);
             }
-            if (q < total) c[u] = B.col[s_base[e] + (q - s_pre[e])];
+            if (q < total) c[u] = B.col[s_base[e] + q];
           }
         }
 #pragma unroll
