@@ -994,17 +994,25 @@ __global__ void __launch_bounds__(64)
           if (col_q[0] == 12345u && bv_q[0] == 0.123) nz++; // the loads have to land before the stamp
 #endif
           SG_STAMP(9)
-          for (uint32_t q0 = 0; q0 < total; q0 += 64) {
-            const uint32_t t_c = t_q[0], col_c = col_q[0];
-            const double bv_c = bv_q[0];
+          // two steps per round: their position searches (five dependent LDS round trips each) are
+          // independent and run side by side; the additions follow in step order
+          static_assert(SLICE_PF >= 2, "two steps are taken from the queue per round");
+          for (uint32_t q0 = 0; q0 < total; q0 += 128) {
+            const uint32_t t_c = t_q[0], col_c = col_q[0], t_d = t_q[1], col_d = col_q[1];
+            const double bv_c = bv_q[0], bv_d = bv_q[1];
 #pragma unroll
-            for (int d = 0; d + 1 < SLICE_PF; ++d) { t_q[d] = t_q[d + 1]; col_q[d] = col_q[d + 1]; bv_q[d] = bv_q[d + 1]; }
-            t_q[SLICE_PF - 1] = 0; col_q[SLICE_PF - 1] = EMPTY_KEY; bv_q[SLICE_PF - 1] = 0.0;
-            if (q0 + 64u * SLICE_PF < total) // flies during the next steps
-              fetchq(q0 + 64u * SLICE_PF + lane, t_q[SLICE_PF - 1], col_q[SLICE_PF - 1], bv_q[SLICE_PF - 1]);
-            const bool valid = col_c != EMPTY_KEY;
-            const uint32_t pos = valid ? find(col_c) : 0u;
-            claim_in_lane_order(vals, owner, stamp, lane, valid, pos, __dmul_rn(avs[t_c], bv_c), hw_order != 0);
+            for (int d = 0; d + 2 < SLICE_PF; ++d) { t_q[d] = t_q[d + 2]; col_q[d] = col_q[d + 2]; bv_q[d] = bv_q[d + 2]; }
+#pragma unroll
+            for (int d = SLICE_PF - 2; d < SLICE_PF; ++d) {
+              t_q[d] = 0; col_q[d] = EMPTY_KEY; bv_q[d] = 0.0;
+              if (q0 + 64u * (uint32_t)(d + 2) < total) // flies during the next rounds
+                fetchq(q0 + 64u * (uint32_t)(d + 2) + lane, t_q[d], col_q[d], bv_q[d]);
+            }
+            const bool valid_c = col_c != EMPTY_KEY, valid_d = col_d != EMPTY_KEY;
+            const uint32_t pos_c = find(valid_c ? col_c : 0u), pos_d = find(valid_d ? col_d : 0u);
+            claim_in_lane_order(vals, owner, stamp, lane, valid_c, pos_c, __dmul_rn(avs[t_c], bv_c), hw_order != 0);
+            if (q0 + 64u < total) // wave-uniform
+              claim_in_lane_order(vals, owner, stamp, lane, valid_d, pos_d, __dmul_rn(avs[t_d], bv_d), hw_order != 0);
           }
           cur += cnt;
           if (act) { // the next column is one of the three looked at, unless the piece was longer
