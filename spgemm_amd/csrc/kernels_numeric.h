@@ -474,6 +474,25 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
         if (ri.rl == 1u) { // wave-uniform
 #pragma unroll
           for (uint32_t j = 0; j < gmaxc; ++j) lds_add_f64(acc_at + j * cap, __dmul_rn(a_of(j, ri.t0), v.bv[0]));
+        } else if (GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX && GMAX * RMAX <= 12) {
+          // a whole run of a small group: the values of ALL rows are asked for first (a dozen at most:
+          // they fit the scalar registers), then the rows' sums advance side by side - row after row,
+          // each row's loads waited for the sums of the row before it, and the chains of additions
+          // (six dependent operations a row) ran one after the other
+          const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri.t0) & 0x7Fu; // (t0 < 128)
+          double a[gmaxc][RMAX], acc[gmaxc];
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j)
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) a[j][r] = a_row[j][tb + (uint32_t)r];
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = acc_at[j * cap];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+            for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a[j][r], v.bv[r]));
+#pragma unroll
+          for (uint32_t j = 0; j < gmaxc; ++j) acc_at[j * cap] = acc[j];
         } else if (GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX) { // a whole run: row after row, each row's values in one go
           const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri.t0) & 0x7Fu; // (t0 < 128)
 #pragma unroll
