@@ -18,6 +18,10 @@ namespace sg {
 // of B with one column list are walked once.
 // LDS per wavefront: bits u32[words] | list of non-empty words u16[words] (rounded up to 16 bytes) | flat-walk scratch
 __host__ __device__ inline size_t sym_window_region(uint32_t words, bool flat) {
+  return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u) + (((size_t)(words + 31u) / 32u * 4u + 15u) & ~(size_t)15u);
+}
+// (the last part: one bit per word of the bitmap, for k_sym_window_runs, behind everything else)
+__host__ __device__ inline size_t sym_window_top_offset(uint32_t words, bool flat) {
   return (((size_t)words * 6u + 15u) & ~(size_t)15u) + (flat ? FLAT_BYTES : 0u);
 }
 // The sorted column list of a row from its bitmap; returns the number of columns.
@@ -41,6 +45,46 @@ __device__ __forceinline__ uint32_t sym_window_emit(const uint32_t *bm, uint16_t
     const uint32_t si = s0 + lane;
     const uint32_t wi = si < nz ? (uint32_t)nzl[si] : 0u;
     uint32_t word = si < nz ? bm[wi] : 0u;
+    const uint32_t pc = __popc(word);
+    const uint32_t incl = group_incl_scan<64>(pc);
+    uint32_t at = carry + incl - pc;
+    carry += group_last<64>(incl);
+    const uint32_t cbase = base + (wi << 5);
+    while (word) {
+      out[at++] = cbase + (uint32_t)__ffs(word) - 1u;
+      word &= word - 1u;
+    }
+  }
+  return carry;
+}
+// The same from a bitmap that comes with a second level (top: one bit per word that holds a column,
+// set by the lane that found the word empty): the words that hold a column are read off the second
+// level - one round for a hull of 65,536 columns instead of 32 over the bitmap - and both levels are
+// left cleared for the next row, which then has nothing to clear either.
+__device__ __forceinline__ uint32_t sym_window_emit_top(uint32_t *bm, uint32_t *top, uint16_t *nzl, uint32_t nw, uint32_t base,
+                                                        uint32_t *__restrict__ out, uint32_t lane) {
+  const uint32_t ntop = (nw + 31u) >> 5;
+  uint32_t nz = 0;
+  for (uint32_t t0 = 0; t0 < ntop; t0 += 64) {
+    const uint32_t ti = t0 + lane;
+    uint32_t tw = ti < ntop ? top[ti] : 0u;
+    const uint32_t pc = __popc(tw);
+    const uint32_t incl = group_incl_scan<64>(pc);
+    uint32_t at = nz + incl - pc;
+    nz += group_last<64>(incl);
+    if (tw) top[ti] = 0u;
+    while (tw) {
+      nzl[at++] = (uint16_t)(ti * 32u + (uint32_t)__ffs(tw) - 1u);
+      tw &= tw - 1u;
+    }
+  }
+  lds_fence();
+  uint32_t carry = 0;
+  for (uint32_t s0 = 0; s0 < nz; s0 += 64) {
+    const uint32_t si = s0 + lane;
+    const uint32_t wi = si < nz ? (uint32_t)nzl[si] : 0u;
+    uint32_t word = si < nz ? bm[wi] : 0u;
+    if (si < nz) bm[wi] = 0u;
     const uint32_t pc = __popc(word);
     const uint32_t incl = group_incl_scan<64>(pc);
     uint32_t at = carry + incl - pc;
@@ -130,6 +174,10 @@ __global__ void __launch_bounds__(256)
   const size_t region = sym_window_region(words, false);
   uint32_t *bm = reinterpret_cast<uint32_t *>(smem + w * region);
   uint16_t *pre = reinterpret_cast<uint16_t *>(smem + w * region + (size_t)words * 4u);
+  uint32_t *top = reinterpret_cast<uint32_t *>(smem + w * region + sym_window_top_offset(words, false));
+  // both levels of the bitmap start empty, and every row leaves them so
+  for (uint32_t i = lane; i < words; i += 64) bm[i] = 0u;
+  for (uint32_t i = lane; i < (words + 31u) / 32u; i += 64) top[i] = 0u;
   const uint32_t st_row = rows[first + min(lane, ng - 1u)];
   const uint32_t st_cmin = m.cmin[st_row], st_cmax = m.cmax[st_row];
   const uint64_t st_toff = m.t_off[st_row], st_a0 = A.ptr[st_row];
@@ -150,17 +198,26 @@ __global__ void __launch_bounds__(256)
     const uint32_t base = rl32(st_cmin, g) & ~31u;
     const uint32_t nw = ((rl32(st_cmax, g) - base) >> 5) + 1u;
     const bool is_long = rl32(st_long, g) != 0u;
-    for (uint32_t i = lane; i < nw; i += 64) bm[i] = 0u;
     cur.len_a = rl32(st_len, g); // (a row without entries cannot be here; the loads above assumed one entry at least)
     cur.finish<255>(lane);
     nxt.issue_b(B, same_bits);
     RowRuns<true> aft;
     aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);
     lds_fence();
+    // (the LDS takes the lanes of one instruction that share a word one after the other: exactly one finds
+    //  it empty and sets the word's bit in the second level - when the NEXT unit is marked, so that no
+    //  unit waits for what its own atomic returns)
+    uint32_t pend_w = 0, pend_old = 1u;
+    auto settle = [&]() {
+      if (pend_old == 0u) atomicOr(&top[pend_w >> 5], 1u << (pend_w & 31u));
+      pend_old = 1u;
+    };
     auto mark = [&](uint32_t col, double, double, uint32_t) {
+      settle();
       if (col == EMPTY_KEY) return;
       const uint32_t c = col - base;
-      atomicOr(&bm[c >> 5], 1u << (c & 31u));
+      pend_w = c >> 5;
+      pend_old = atomicOr(&bm[pend_w], 1u << (c & 31u));
     };
     if (!is_long) { // wave-uniform
       RunPipe<255, false, SYM_RUN_SLOTS, true> pipe;
@@ -169,10 +226,11 @@ __global__ void __launch_bounds__(256)
     } else {
       wave_row_walk<false, false, false>(A, B, row, lane, mark, same_bits); // (an entry that repeats a column list is skipped)
     }
+    settle();
     lds_fence();
-    const uint32_t n = sym_window_emit(bm, pre, nw, base, m.temp_cols + readlane64(st_toff, g), lane);
+    const uint32_t n = sym_window_emit_top(bm, top, pre, nw, base, m.temp_cols + readlane64(st_toff, g), lane);
     sym_window_finish(A, m, row, n, lane);
-    lds_fence(); // the next row clears the bitmap
+    lds_fence(); // (both levels are empty again)
     cur = nxt;
     nxt = aft;
   }
