@@ -162,6 +162,8 @@ __global__ void __launch_bounds__(256)
 // column sits behind a chain of dependent loads (row id -> row state -> column indices of the A row ->
 // bounds of the B rows -> B entries); the chain is taken off the critical path as in k_num_grp_run:
 // lane i holds row i's state, the description of the next row is loaded while this one is walked.
+// PAIR: the units are 128 columns of a B row, two per lane (for a B whose rows have more than 64 entries)
+template <bool PAIR>
 __global__ void __launch_bounds__(256)
     k_sym_window_runs(const uint32_t *__restrict__ rows, uint32_t nrows, Csr A, Csr B, RowMeta m, uint32_t words,
                       const uint32_t *__restrict__ same_bits, uint32_t wpb, uint32_t rpw) {
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256)
   const uint32_t st_len = (uint32_t)min(st_len64, (uint64_t)128u); // what the registers describe
   const uint32_t st_long = st_len64 > 128u ? 1u : 0u;              // such a row is walked through scalar loads
   auto rl32 = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
-  RowRuns<true> cur, nxt;
+  RowRuns<true, true, PAIR> cur, nxt;
   cur.issue_a(A, readlane64(st_a0, 0), max(rl32(st_len, 0), 1u), lane);
   {
     const uint32_t g1 = min(1u, ng - 1u);
@@ -199,9 +201,9 @@ __global__ void __launch_bounds__(256)
     const uint32_t nw = ((rl32(st_cmax, g) - base) >> 5) + 1u;
     const bool is_long = rl32(st_long, g) != 0u;
     cur.len_a = rl32(st_len, g); // (a row without entries cannot be here; the loads above assumed one entry at least)
-    cur.finish<255>(lane);
+    cur.template finish<255>(lane);
     nxt.issue_b(B, same_bits);
-    RowRuns<true> aft;
+    RowRuns<true, true, PAIR> aft;
     aft.issue_a(A, readlane64(st_a0, g2), max(rl32(st_len, g2), 1u), lane);
     lds_fence();
     // (the LDS takes the lanes of one instruction that share a word one after the other: exactly one finds
@@ -220,9 +222,12 @@ __global__ void __launch_bounds__(256)
       pend_old = atomicOr(&bm[pend_w], 1u << (c & 31u));
     };
     if (!is_long) { // wave-uniform
-      RunPipe<255, false, SYM_RUN_SLOTS, true> pipe;
+      RunPipe<255, false, SYM_RUN_SLOTS, true, PAIR> pipe;
       pipe.begin(B, cur, lane);
-      pipe.run(B, cur, lane, [&](const RunInfo &, const RunVec<1> &v) { mark(v.ok ? v.col : EMPTY_KEY, 0.0, 0.0, 0u); });
+      pipe.run(B, cur, lane, [&](const RunInfo &, const RunVec<1, PAIR> &v) {
+        mark(v.ok ? v.col : EMPTY_KEY, 0.0, 0.0, 0u);
+        if constexpr (PAIR) mark(v.ok2 ? v.col2 : EMPTY_KEY, 0.0, 0.0, 0u);
+      });
     } else {
       wave_row_walk<false, false, false>(A, B, row, lane, mark, same_bits); // (an entry that repeats a column list is skipped)
     }

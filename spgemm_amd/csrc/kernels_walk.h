@@ -235,15 +235,21 @@ struct RunInfo { // wave-uniform
   uint32_t chunk;
   bool valid;
 };
-template <int NV> struct RunVec {
+// PAIR: a unit is 128 columns of its rows, two per lane (col2 / ok2 / bv2: the column 64 further on): half
+// as many units for rows of B with 65 to 128 entries, whose second 64 columns fill a quarter of the lanes
+template <int NV, bool PAIR = false> struct RunVec {
   uint32_t col;     // the lane's column of this unit
   bool ok;          // ... if it holds one
   double bv[NV];    // the column's value in the run's rows (rows past the run's end repeat the last one); pattern walks: unused
+  uint32_t col2;
+  bool ok2;
+  double bv2[NV];
 };
 // TABLE: the units are laid out by the vector unit (below); else they are enumerated on the scalar unit,
 // one at a time (the kernels of the narrow groups: their walk is short, and the tables' registers
 // cost them a fifth of their wavefronts per CU)
-template <bool WIDE, bool TABLE = true> struct RowRuns {
+template <bool WIDE, bool TABLE = true, bool PAIR = false> struct RowRuns {
+  static_assert(TABLE || !PAIR, "units of 128 columns come with the unit tables");
   static constexpr bool table = TABLE;
   // per lane: entry t (lo) and 64 + t (hi, WIDE only)
   uint64_t p0_lo, p0_hi;
@@ -342,7 +348,7 @@ template <bool WIDE, bool TABLE = true> struct RowRuns {
     const uint32_t tn = after ? lane + 1u + (uint32_t)__builtin_ctzll(after) : tail;
     rows = tn - lane;
     const uint32_t len = hi ? len_hi : len_lo;
-    const uint32_t nch = ((rs >> lane) & 1ull) ? (len + 63u) >> 6 : 0u;
+    const uint32_t nch = ((rs >> lane) & 1ull) ? (PAIR ? (len + 127u) >> 7 : (len + 63u) >> 6) : 0u;
     const uint32_t incl = group_incl_scan<64>(nch);
     base = incl - nch;
     ph_tot = group_last<64>(incl);
@@ -473,15 +479,23 @@ template <bool WIDE, bool TABLE = true> struct RowRuns {
 // a row past the end of the run and an exhausted walk read an address that is always valid: the
 // run's first entry, or entry 0 of B): the number of loads in flight is then the same on every path
 // through the loop, which lets the compiler wait for exactly the unit it is about to consume.
-template <int RMAX, bool WITH_VAL>
-__device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32_t lane, RunVec<WITH_VAL ? RMAX : 1> &v) {
-  const uint32_t j = s.chunk * 64u + lane;
+template <int RMAX, bool WITH_VAL, bool PAIR = false>
+__device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32_t lane, RunVec<WITH_VAL ? RMAX : 1, PAIR> &v) {
+  const uint32_t j = s.chunk * (PAIR ? 128u : 64u) + lane;
   v.ok = s.valid && j < s.L;
   const uint64_t base = (s.valid && s.L) ? s.p0 : 0ull;
   // (the rows of B walked here are strictly increasing rows of a window row: at most 65,536 entries.
   //  The mask tells the compiler that the byte offset fits 32 bits: scalar base + 32-bit lane offset.)
   const uint32_t jj = (v.ok ? j : 0u) & 0xFFFFFu;
   v.col = (B.col + base)[jj];
+  uint32_t jj2 = 0;
+  v.ok2 = false;
+  v.col2 = 0;
+  if constexpr (PAIR) {
+    v.ok2 = s.valid && j + 64u < s.L;
+    jj2 = (v.ok2 ? j + 64u : 0u) & 0xFFFFFu;
+    v.col2 = (B.col + base)[jj2];
+  }
   if constexpr (WITH_VAL) {
     // (the lane reads say so to the compiler: scalar base + 32-bit lane offset, no 64-bit address per lane and row)
     const uint64_t vbp = (uint64_t)(uintptr_t)(B.val + base);
@@ -493,6 +507,7 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
     for (int r = 0; r < RMAX; ++r) { // a row of the run: its own base on the scalar unit, the lanes' offset is the same for all rows
       const uint32_t rr = min((uint32_t)r, s.rl - 1u);
       v.bv[r] = ((global_f64_ptr)(uintptr_t)(vb + (uint64_t)(rr * s.L) * 8u))[jj];
+      if constexpr (PAIR) v.bv2[r] = ((global_f64_ptr)(uintptr_t)(vb + (uint64_t)(rr * s.L) * 8u))[jj2];
     }
   }
 }
@@ -500,14 +515,14 @@ __device__ __forceinline__ void run_fetch(const Csr &B, const RunInfo &s, uint32
 // The units of a row, SLOTS of them in flight: begin() issues the first SLOTS fetches (to be
 // overlapped with the kernel's set-up), run() consumes a unit and refills its slot.
 // f(info, vec) is called once per unit by all lanes.
-template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
+template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE, bool PAIR = false> struct RunPipe {
   RunInfo info[SLOTS];
-  RunVec<WITH_VAL ? RMAX : 1> vec[SLOTS];
+  RunVec<WITH_VAL ? RMAX : 1, PAIR> vec[SLOTS];
   template <class RR> __device__ __forceinline__ void begin(const Csr &B, RR &rr, uint32_t lane) {
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       info[s] = rr.template next<RMAX>();
-      run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+      run_fetch<RMAX, WITH_VAL, PAIR>(B, info[s], lane, vec[s]);
     }
   }
   template <class RR, class F> __device__ __forceinline__ void run(const Csr &B, RR &rr, uint32_t lane, F f) {
@@ -518,7 +533,7 @@ template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
           if (!info[s].valid) return; // the units come in order: the first empty slot ends the walk
           f(info[s], vec[s]);
           info[s] = rr.template next<RMAX>();
-          run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+          run_fetch<RMAX, WITH_VAL, PAIR>(B, info[s], lane, vec[s]);
         }
       }
     }
@@ -530,7 +545,7 @@ template <int RMAX, bool WITH_VAL, int SLOTS, bool WIDE> struct RunPipe {
           if (!info[s].valid) { open = false; break; } // the units come in order: the first empty slot ends the table
           f(info[s], vec[s]);
           info[s] = rr.template next<RMAX>();
-          run_fetch<RMAX, WITH_VAL>(B, info[s], lane, vec[s]);
+          run_fetch<RMAX, WITH_VAL, PAIR>(B, info[s], lane, vec[s]);
         }
       }
       if (!rr.more()) return;

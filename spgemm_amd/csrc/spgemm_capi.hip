@@ -496,7 +496,7 @@ template <class K> static void raise_lds_limit(K kernel) {
 }
 static void raise_all_lds_limits() { // per device: called with the context's device current
   raise_lds_limit(k_sym_window<true>); raise_lds_limit(k_sym_window<false>); raise_lds_limit(k_sym_window<false, true>);
-  raise_lds_limit(k_sym_window_runs);
+  raise_lds_limit(k_sym_window_runs<false>); raise_lds_limit(k_sym_window_runs<true>);
   raise_lds_limit(k_num_window_grp<0, false>); raise_lds_limit(k_num_window_grp<1, false>); raise_lds_limit(k_num_window_grp<2, false>);
   raise_lds_limit(k_num_window_grp<0, true>); raise_lds_limit(k_num_window_grp<1, true>); raise_lds_limit(k_num_window_grp<2, true>);
   raise_lds_limit(k_num_window_grp<0, false, true>); raise_lds_limit(k_num_window_grp<1, false, true>); raise_lds_limit(k_num_window_grp<2, false, true>);
@@ -1308,7 +1308,9 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
       if (!flat && same_bits && ctx->sym_rpw > 1) {
         // B has runs of rows with one column list: the kernel whose wavefronts take several rows, the next one's description in flight
         const uint32_t rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->sym_rpw, ctx->rpw_fill ? cnt / ((uint64_t)ctx->cu_count * 32 * ctx->rpw_fill) : cnt));
-        hipLaunchKernelGGL(k_sym_window_runs, dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream,
+        // (units of 128 columns where the rows of B have more than 64 entries on average)
+        hipLaunchKernelGGL(B->nnz > 64 * B->rows ? k_sym_window_runs<true> : k_sym_window_runs<false>,
+                           dim3(div_up_u64(cnt, (uint64_t)wpb * rpw)), dim3(64 * wpb), region * wpb, ctx->stream,
                            rows_bin, cnt, cA, cB, rm, words, same_bits, wpb, rpw);
       } else
       hipLaunchKernelGGL(sym_kern, dim3(div_up_u64(cnt, wpb)), dim3(64 * wpb),
