@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
 #pragma unroll
     for (uint32_t u = 0; u < TCN; ++u) tc[u] = tin[min(64u * u + lane, n - 1u)];
   };
-  using Runs = RowRuns<WIDE, WIDE>; // (the narrow groups: units enumerated on the scalar unit)
+  using Runs = RowRuns<WIDE, WIDE, WIDE>; // (the narrow groups: units enumerated on the scalar unit; the wide ones: units of 128 columns, two per lane)
   Runs cur, nxt;
   auto len_of = [&](uint32_t g) { return (rl32(st_pack, g) >> 8) & 0xFFu; };
   cur.issue_a(A, readlane64(st_a0, 0), max(len_of(0), 1u), lane);
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
       }
     }
     // the first units' B entries: in flight during the rest of the set-up
-    RunPipe<RMAX, true, GRP_RUN_SLOTS, WIDE> pipe;
+    RunPipe<RMAX, true, GRP_RUN_SLOTS, WIDE, WIDE> pipe;
     pipe.begin(B, cur, lane);
     lds_fence();
     // (a row's base on the scalar unit, the position as a 32-bit lane offset: no 64-bit address per lane and row)
@@ -464,33 +464,39 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
       else if constexpr (WIDE) return t < 64u ? readlane_f64(av_lo[j], t) : readlane_f64(av_hi[j], t - 64u);
       else return readlane_f64(av_lo[j], t);
     };
-    pipe.run(B, cur, lane, [&](const RunInfo &ri, const RunVec<RMAX> &v) {
+    pipe.run(B, cur, lane, [&](const RunInfo &ri, const RunVec<RMAX, WIDE> &v) {
       lds_fence(); // the unit before has left its sums in LDS
-      if (v.ok) {
-        const uint32_t cc = v.col - base;
+      // a whole run of a small group: the values of ALL rows are asked for first (a dozen at most:
+      // they fit the scalar registers), then the rows' sums advance side by side - row after row,
+      // each row's loads waited for the sums of the row before it, and the chains of additions
+      // (six dependent operations a row) ran one after the other
+      const bool whole_small = GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX && GMAX * RMAX <= 12; // wave-uniform
+      double a[gmaxc][RMAX];
+      if (whole_small) {
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri.t0) & 0x7Fu; // (t0 < 128)
+#pragma unroll
+        for (uint32_t j = 0; j < gmaxc; ++j)
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) a[j][r] = a_row[j][tb + (uint32_t)r];
+      }
+      // one column per lane of the unit (a wide group's unit has two: the second 64 columns of the B rows)
+      auto half = [&](bool ok, uint32_t col, const double (&bv)[RMAX]) {
+      if (ok) {
+        const uint32_t cc = col - base;
         const uint64_t e = cw[compact_word(cc >> 5)];
         const uint32_t pos = (uint32_t)(e >> 32) + __popc((uint32_t)e & ((1u << (cc & 31u)) - 1u));
         double *acc_at = vals + pos;
         if (ri.rl == 1u) { // wave-uniform
 #pragma unroll
-          for (uint32_t j = 0; j < gmaxc; ++j) lds_add_f64(acc_at + j * cap, __dmul_rn(a_of(j, ri.t0), v.bv[0]));
-        } else if (GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX && GMAX * RMAX <= 12) {
-          // a whole run of a small group: the values of ALL rows are asked for first (a dozen at most:
-          // they fit the scalar registers), then the rows' sums advance side by side - row after row,
-          // each row's loads waited for the sums of the row before it, and the chains of additions
-          // (six dependent operations a row) ran one after the other
-          const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ri.t0) & 0x7Fu; // (t0 < 128)
-          double a[gmaxc][RMAX], acc[gmaxc];
-#pragma unroll
-          for (uint32_t j = 0; j < gmaxc; ++j)
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) a[j][r] = a_row[j][tb + (uint32_t)r];
+          for (uint32_t j = 0; j < gmaxc; ++j) lds_add_f64(acc_at + j * cap, __dmul_rn(a_of(j, ri.t0), bv[0]));
+        } else if (whole_small) {
+          double acc[gmaxc];
 #pragma unroll
           for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = acc_at[j * cap];
 #pragma unroll
           for (int r = 0; r < RMAX; ++r)
 #pragma unroll
-            for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a[j][r], v.bv[r]));
+            for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a[j][r], bv[r]));
 #pragma unroll
           for (uint32_t j = 0; j < gmaxc; ++j) acc_at[j * cap] = acc[j];
         } else if (GRP_RUN_ASCALAR && ri.rl == (uint32_t)RMAX) { // a whole run: row after row, each row's values in one go
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
             for (int r = 0; r < RMAX; ++r) a[r] = a_row[j][tb + (uint32_t)r]; // (one masked entry number + constants: adjacent loads merge)
             double acc = acc_at[j * cap];
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) acc = __dadd_rn(acc, __dmul_rn(a[r], v.bv[r]));
+            for (int r = 0; r < RMAX; ++r) acc = __dadd_rn(acc, __dmul_rn(a[r], bv[r]));
             acc_at[j * cap] = acc;
           }
         } else {
@@ -513,12 +519,15 @@ __global__ void __launch_bounds__(256, WIDE ? 1 : SG_GRP_WPE)
           for (int r = 0; r < RMAX; ++r)
             if ((uint32_t)r < ri.rl) { // wave-uniform
 #pragma unroll
-              for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a_of(j, ri.t0 + (uint32_t)r), v.bv[r]));
+              for (uint32_t j = 0; j < gmaxc; ++j) acc[j] = __dadd_rn(acc[j], __dmul_rn(a_of(j, ri.t0 + (uint32_t)r), bv[r]));
             }
 #pragma unroll
           for (uint32_t j = 0; j < gmaxc; ++j) acc_at[j * cap] = acc[j];
         }
       }
+      };
+      half(v.ok, v.col, v.bv);
+      if constexpr (WIDE) half(v.ok2, v.col2, v.bv2);
     });
     lds_fence();
     asm volatile("" ::"v"(a_touch)); // (keeps the load above)
