@@ -101,6 +101,8 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   short-row kernels (count-only symbolic pass, numeric
  *                                                   pass that sorts the row's products itself); 0: none
  *   short_rpw                                       rows one wavefront of those kernels pipelines
+ *   short_num_rpw                                   ... of the numeric one (default 8; its wavefronts take
+ *                                                   rows a launch-wide stride apart)
  *   analyze_lanes                                   lanes per row of A in the analysis: 8, 16, 32, or
  *                                                   0 (default) = by the mean row length
  *   short_key32                                     1 (default): 32-bit entries in the sorting table

@@ -314,9 +314,15 @@ __global__ void __launch_bounds__(256)
   using key_t = typename std::conditional<K32, uint32_t, unsigned long long>::type;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint64_t first64 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w) * rpw;
-  if (w >= wpb || first64 >= nrows) return;
-  const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)nrows, first64 + rpw);
+  // Wavefront g of the launch's nw takes the rows g, g + nw, g + 2 nw, ... of the bin (at most rpw: the
+  // grid is sized so): the rows in work at one time are neighbours in the bin, and so are the pieces of
+  // C being written (with rpw rows in a block per wavefront the writes of a moment were spread over
+  // rpw times as much of C, which cost a tenth of the kernel's time).
+  const uint64_t g64 = (uint64_t)xcd_remap(blockIdx.x, gridDim.x) * wpb + w;
+  const uint64_t nw = (uint64_t)gridDim.x * wpb;
+  if (w >= wpb || g64 >= nrows) return;
+  const uint32_t count = (uint32_t)min((uint64_t)rpw, ((uint64_t)nrows - g64 + nw - 1u) / nw);
+  auto idx_of = [&](uint32_t i) { return (uint32_t)(g64 + (uint64_t)i * nw); };
   const uint32_t PM = 1u << log2pm;
   const uint32_t cshift = K32 ? log2pm : 32u; // an entry is column << cshift | product number
   const size_t region = ((size_t)(K32 ? 20u : 32u) << log2pm) + sh_scratch(true, STEPS);
@@ -332,10 +338,10 @@ __global__ void __launch_bounds__(256)
   ShortFetch fa;
   ShortSet<true, STEPS> cur, nxt;
   const double *avs = reinterpret_cast<const double *>(scratch + 768 + 64 * STEPS);
-  short_fetch<true>(A, B, m, cm, o.c_ptr, rows, first, lane, fa);
+  short_fetch<true>(A, B, m, cm, o.c_ptr, rows, idx_of(0), lane, fa);
   short_expand<true, STEPS>(B, cm, fa, lane, scratch, PM, cur);
-  if (first + 1u < last) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, first + 1u, lane, fa);
-  for (uint32_t i = first; i < last; ++i) {
+  if (1u < count) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, idx_of(1), lane, fa);
+  for (uint32_t i = 0; i < count; ++i) {
     const uint32_t total = min(cur.total, PM), n = cur.n;
     const uint64_t off = cur.off;
     const uint32_t H = 2u * total, T = (3u * total + 63u) & ~63u; // slots in use: a multiple of 64, <= 3 PM
@@ -370,9 +376,9 @@ __global__ void __launch_bounds__(256)
     }
     // the row's values and A entries are used up: the next row is expanded now (its B entries are in
     // flight during the rest of this row, and only half as many registers are live across the loads)
-    if (i + 1u < last) {
+    if (i + 1u < count) {
       short_expand<true, STEPS>(B, cm, fa, lane, scratch, PM, nxt);
-      if (i + 2u < last) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, i + 2u, lane, fa);
+      if (i + 2u < count) short_fetch<true>(A, B, m, cm, o.c_ptr, rows, idx_of(i + 2u), lane, fa);
     }
     // 1. sorted insertion; the chains of a lane's products advance together: the atomics of a round
     //    are issued back to back, their results read afterwards, no branch in between (the minimum

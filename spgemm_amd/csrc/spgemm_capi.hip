@@ -126,6 +126,7 @@ struct spgemm_ctx {
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
   uint32_t hash_num_slice = 1024; // LDS-hash numeric rows with more outputs go to the slice kernel
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
+  uint32_t short_num_rpw = 8;    // ... of the numeric one (its wavefronts take rows a launch-wide stride apart)
   uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
   uint32_t rpw_fill = 16;        // ... but no more than leave this many wavefronts of work per wavefront slot of the device (0: no such limit)
@@ -479,10 +480,12 @@ static uint32_t pick_wpb(size_t region) {
 }
 
 // Rows a wavefront of the short-row kernels takes one after the other (it pipelines their loads):
-// as many as leave about 64 wavefronts of work per CU, at most short_rpw.
-static uint32_t short_rows_per_wave(const spgemm_ctx *ctx, uint32_t rows) {
+// as many as leave about 64 wavefronts of work per CU (rpw_fill = 0: no such limit, so that small
+// inputs reach the pipelined form too), at most short_rpw.
+static uint32_t short_rows_per_wave(const spgemm_ctx *ctx, uint32_t rows, bool numeric = false) {
   const uint64_t waves = (uint64_t)ctx->cu_count * 64;
-  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ctx->short_rpw, rows / waves));
+  const uint64_t most = numeric ? ctx->short_num_rpw : ctx->short_rpw;
+  return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(most, ctx->rpw_fill ? rows / waves : rows));
 }
 
 // ---- LDS limits ------------------------------------------------------------------------------------
@@ -763,6 +766,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "short_rpw") {
     if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "short_rpw must be 1..4096");
     ctx->short_rpw = (uint32_t)value;
+  } else if (n == "short_num_rpw") {
+    if (value < 1 || value > 4096) return fail(SPGEMM_ERR_INVALID, "short_num_rpw must be 1..4096");
+    ctx->short_num_rpw = (uint32_t)value;
   } else if (n == "flat_walk") {
     ctx->flat_walk = value != 0;
   } else if (n == "row_groups") {
@@ -1568,7 +1574,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       if (pl.a_pk) TRY(ensure_prec(ctx, B));
       ColMap cm{B->d_colcdf, B->cdf_shift, 1.0f / (float)(1ull << B->cdf_shift), pl.a_pk ? B->d_prec : nullptr, nullptr};
       TRY(prof_begin(ctx, 1, 1, 1, cnt, log2pm, 0, region * wpb, rows_bin));
-      const uint32_t rpw = short_rows_per_wave(ctx, cnt);
+      const uint32_t rpw = short_rows_per_wave(ctx, cnt, true);
       const bool four = num_short_steps(log2pm) == 4;
       auto kern = k32 ? (four ? k_num_short<4, true> : k_num_short<SH_STEPS, true>)
                       : (four ? k_num_short<4, false> : k_num_short<SH_STEPS, false>);

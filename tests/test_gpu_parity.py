@@ -115,6 +115,28 @@ def test_short_rows_slot_layout_boundaries(len_b):
                 c.close()
 
 
+@pytest.mark.parametrize("rpw_sym,rpw_num", [(3, 3), (16, 8), (5, 64)])
+def test_short_rows_several_per_wavefront(rpw_sym, rpw_num):
+    """The short-row kernels with several rows per wavefront (a small input takes one per wavefront
+    unless rpw_fill is 0): the symbolic one takes consecutive rows, the numeric one rows a launch-wide
+    stride apart, both with the next rows' loads in flight; row counts that leave the last
+    wavefronts with fewer rows than the others."""
+    for n, per_row in ((4099, 12), (1000, 16), (37, 5)):
+        A = hostcsr.erdos_renyi(n, per_row, seed=n)
+        c = capi.Context(0)
+        try:
+            c.set_option("window_max_span", 0)  # nothing takes the window path
+            c.set_option("rpw_fill", 0)
+            c.set_option("short_rpw", rpw_sym)
+            c.set_option("short_num_rpw", rpw_num)
+            c.set_option("profile_launches", 1)
+            _, st = check(c, A, A)
+            assert st["rows_hash"] > 0
+            assert any(l["phase"] == "numeric" and l["path"] == "hash" and l["lanes"] == 1 for l in c.launches())
+        finally:
+            c.close()
+
+
 def test_rmat_default_paths(ctx):
     A = hostcsr.rmat(13, 8, seed=1)
     check(ctx, A, A)
