@@ -393,6 +393,47 @@ def test_row_runs_half_boundary_and_empty_b_rows(ctx):
             ctx.set_option("rpw_fill", 16)
 
 
+def test_row_runs_units_of_128_columns_boundaries(ctx):
+    # B made of blocks of identical rows whose lengths sit on either side of the 64- and 128-column
+    # marks (63 .. 257: one to three units of 128 columns, the second half of a unit empty, partly or
+    # wholly filled), with more than 64 entries per row on average, so that the symbolic run kernel
+    # takes units of 128 columns as the numeric kernel of the wide groups always does; A rows of 1 .. 128
+    # entries that select consecutive B rows, every A row twice (groups)
+    rng = np.random.default_rng(128)
+    dof, cols = 3, 420
+    lens = [63, 64, 65, 127, 128, 129, 191, 192, 193, 256, 257, 1, 130, 66, 200, 100] * 3
+    nb = len(lens) * dof
+    br, bc = [], []
+    for blk, L in enumerate(lens):
+        cl = np.sort(rng.choice(cols, L, replace=False))
+        for i in range(dof):
+            br.append(np.full(L, blk * dof + i))
+            bc.append(cl)
+    br, bc = np.concatenate(br), np.concatenate(bc)
+    B = hostcsr.HostCsr.from_coo(nb, cols, br, bc, rng.random(len(br)) * 2 - 1)
+    assert B.nnz > 64 * B.rows
+    ar, ac = [], []
+    row = 0
+    for ln in (1, 3, 6, 33, 63, 64, 65, 66, 96, 127, 128):
+        for start in (0, 2, int(rng.integers(0, nb - 128))):
+            ks = np.arange(start, start + ln)
+            for _ in range(2):
+                ar.append(np.full(ln, row))
+                ac.append(ks)
+                row += 1
+    ar, ac = np.concatenate(ar), np.concatenate(ac)
+    A = hostcsr.HostCsr.from_coo(row, nb, ar, ac, rng.random(len(ar)) * 2 - 1)
+    for fill in (16, 0):
+        ctx.set_option("rpw_fill", fill)
+        ctx.set_option("profile_launches", 1)
+        try:
+            check(ctx, A, B)
+            assert any(l["phase"] == "numeric" and l["path"] == "window_group_runs" for l in ctx.launches())
+        finally:
+            ctx.set_option("rpw_fill", 16)
+            ctx.set_option("profile_launches", 0)
+
+
 def test_row_groups_with_cancellation_and_order(ctx):
     # identical column lists but stored in a different order must NOT be grouped (the k order
     # differs); identical rows whose values cancel exactly are dropped per row
