@@ -526,7 +526,8 @@ struct SliceItem {
 // run_min >= 4; run_div: entries of the A row per chunk of a run
 __host__ __device__ inline uint32_t slice_run(uint32_t len_a, uint32_t run_min, uint32_t run_div) {
   uint32_t g = len_a / run_div;
-  return g < run_min ? run_min : g > 64u ? 64u : g;
+  const uint32_t most = run_min > 64u ? run_min : 64u;
+  return g < run_min ? run_min : g > most ? most : g;
 }
 
 __global__ void __launch_bounds__(256)
@@ -544,18 +545,39 @@ __global__ void __launch_bounds__(256)
     k_slice_fill(const uint32_t *__restrict__ rows, uint32_t nrows, const uint64_t *__restrict__ a_ptr,
                  const uint32_t *__restrict__ nnz, const uint64_t *__restrict__ offset,
                  SliceItem *__restrict__ items, uint32_t *__restrict__ keys, RowMeta m, uint32_t run_min,
-                 uint32_t run_div) {
+                 uint32_t run_div, uint32_t by_cost) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nrows) return;
   const uint32_t row = rows[i];
   const uint32_t chunks = (nnz[row] + SLICE_W - 1u) / SLICE_W;
   const uint32_t g = slice_run((uint32_t)(a_ptr[row + 1] - a_ptr[row]), run_min, run_div);
   const uint32_t *tin = keys ? m.temp_cols + m.t_off[m.lead[row]] : nullptr;
+  const uint64_t len_a = a_ptr[row + 1] - a_ptr[row];
   uint64_t o = offset[i];
   for (uint32_t c = 0; c < chunks; c += g) {
-    if (keys) keys[o] = tin[(size_t)c * SLICE_W]; // the item's first output column: the sort key
-    items[o++] = SliceItem{row, c, min(g, chunks - c)};
+    const uint32_t nc = min(g, chunks - c);
+    // the sort key: the item's first output column, or (by_cost) what the item costs, the dearest first:
+    // every chunk walks the item's list of A entries and adds a chunk's worth of products
+    if (keys) keys[o] = by_cost ? 0xFFFFFFFEu - (uint32_t)min((uint64_t)0xFFFFFFF0u, (uint64_t)nc * (len_a + SLICE_W)) : tin[(size_t)c * SLICE_W];
+    items[o++] = SliceItem{row, c, nc};
   }
+}
+
+// Rows of the big-row symbolic bin in the order of their cost: sort keys (dearest first) and records
+// {row, 0, 0} for the 12-byte record sort, and the row ids back out of the sorted records.
+__global__ void __launch_bounds__(256)
+    k_big_order_fill(const uint32_t *__restrict__ rows, uint32_t nrows, const uint32_t *__restrict__ ub,
+                     uint32_t *__restrict__ keys, SliceItem *__restrict__ recs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const uint32_t row = rows[i];
+  keys[i] = ~ub[row];
+  recs[i] = SliceItem{row, 0u, 0u};
+}
+__global__ void __launch_bounds__(256)
+    k_big_order_rows(const SliceItem *__restrict__ recs, uint32_t nrows, uint32_t *__restrict__ rows_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nrows) rows_out[i] = recs[i].row;
 }
 
 // longest A row among the rows of the numeric phase's big-row bin (atomic max into out[0], zero on entry)

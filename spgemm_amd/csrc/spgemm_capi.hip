@@ -118,9 +118,9 @@ struct spgemm_ctx {
                                  // 2 where B's rows hold 48 entries and more on average
   uint32_t short_packed = 2;     // 1: the short-row numeric kernel reads B's rows as padded 16-byte records; 2: and the
                                  // count-only symbolic kernel their columns from a padded array of its own
-  uint32_t slice_run_min = 4;    // chunks in a run of the slice kernel: at least this many (4..64) ...
+  uint32_t slice_run_min = 64;   // chunks in a run of the slice kernel: at least this many (4..65536) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
-  uint32_t slice_sorted = 0;     // 1: the slice kernel takes its items in the order of their first column
+  uint32_t slice_sorted = 2;     // the slice kernel takes its items 0: in row order; 1: in the order of their first column; 2: the dearest first
   uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 12-byte {column, value} records
   uint32_t slice_sampled = 1;    // 1: its searches inside rows of B go over a 1-in-32 sample of B's columns first
   uint32_t big_win_words = 32768; // bitmap window of the big-row symbolic kernel, in 32-column words
@@ -128,6 +128,7 @@ struct spgemm_ctx {
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
   uint32_t short_num_rpw = 8;    // ... of the numeric one (its wavefronts take rows a launch-wide stride apart)
   uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
+  uint32_t big_sym_sorted = 1;   // ... takes its rows the dearest first (0: in row order)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
   uint32_t rpw_fill = 16;        // ... but no more than leave this many wavefronts of work per wavefront slot of the device (0: no such limit)
   uint32_t grp_rpw = 8;          // most groups one wavefront of the run kernel takes one after the other (<= 64)
@@ -809,6 +810,9 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "walk_tail") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "walk_tail must be 0, 1 or 2");
     ctx->walk_tail = (uint32_t)value;
+  } else if (n == "big_sym_sorted") {
+    if (value > 1) return fail(SPGEMM_ERR_INVALID, "big_sym_sorted must be 0 or 1");
+    ctx->big_sym_sorted = (uint32_t)value;
   } else if (n == "big_sym_bounds") {
     if (value > 1) return fail(SPGEMM_ERR_INVALID, "big_sym_bounds must be 0 or 1");
     ctx->big_sym_bounds = (uint32_t)value;
@@ -828,13 +832,13 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "short_packed must be 0, 1 or 2");
     ctx->short_packed = (uint32_t)value;
   } else if (n == "slice_run_min") {
-    if (value < 4 || value > 64) return fail(SPGEMM_ERR_INVALID, "slice_run_min must be 4..64");
+    if (value < 4 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_run_min must be 4..65536");
     ctx->slice_run_min = (uint32_t)value;
   } else if (n == "slice_run_div") {
     if (value < 1 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_run_div must be 1..65536");
     ctx->slice_run_div = (uint32_t)value;
   } else if (n == "slice_sorted") {
-    if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0 or 1");
+    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0, 1 or 2");
     ctx->slice_sorted = (uint32_t)value;
   } else if (n == "slice_sampled") {
     if (value < 0 || value > 1) return fail(SPGEMM_ERR_INVALID, "slice_sampled must be 0 or 1");
@@ -1373,8 +1377,27 @@ static int run_symbolic(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *
         // the pieces of B's rows per bitmap window are known in advance: no cursors, independent loads
         const uint32_t win_words = 1u << (B->wb_ws - 5u);
         const size_t lds = sym_big2_lds(win_words);
+        // The rows in the order of what they cost (their products, as far as the upper bound of the row's
+        // outputs tells), the dearest first: a workgroup takes one row, the rows of a hub are a hundred
+        // times the mean, and one that starts late is what the launch ends on.
+        const uint32_t *rows_use = rows_bin;
+        if (ctx->big_sym_sorted && cnt > 1) {
+          const size_t b_keys = align_up((size_t)cnt * 4, 256), b_rec = align_up((size_t)cnt * 12, 256);
+          size_t b_tmp = 0;
+          TRY(spgemm_internal_sort_records12(ctx->stream, nullptr, nullptr, nullptr, nullptr, cnt, nullptr, &b_tmp));
+          b_tmp = align_up(b_tmp, 256);
+          TRY(grow(ctx, ctx->big_cur, 2 * b_keys + 2 * b_rec + b_tmp)); // (the cursor walk's buffer: not in use on this path)
+          char *bb = reinterpret_cast<char *>(ctx->big_cur.p);
+          uint32_t *key_in = reinterpret_cast<uint32_t *>(bb), *key_out = reinterpret_cast<uint32_t *>(bb + b_keys);
+          SliceItem *rec_in = reinterpret_cast<SliceItem *>(bb + 2 * b_keys), *rec_out = reinterpret_cast<SliceItem *>(bb + 2 * b_keys + b_rec);
+          void *tmp = bb + 2 * b_keys + 2 * b_rec;
+          hipLaunchKernelGGL(k_big_order_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, r_ub, key_in, rec_in);
+          TRY(spgemm_internal_sort_records12(ctx->stream, key_in, key_out, rec_in, rec_out, cnt, tmp, &b_tmp));
+          hipLaunchKernelGGL(k_big_order_rows, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rec_out, cnt, key_in);
+          rows_use = key_in;
+        }
         TRY(prof_begin(ctx, 0, 4, BIG_THREADS, cnt, win_words, 1, lds, rows_bin));
-        hipLaunchKernelGGL(k_sym_big2, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_bin, cnt, cA, cB, rm, B->d_wb,
+        hipLaunchKernelGGL(k_sym_big2, dim3(cnt), dim3(BIG_THREADS), lds, ctx->stream, rows_use, cnt, cA, cB, rm, B->d_wb,
                            B->wb_nwin, B->wb_ws);
 #ifdef SG_SYM2_STAMPS
         {
@@ -1640,7 +1663,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       TRY(launch_scan(ctx, s_count, cnt, s_off, partial));
       if (sort_n) HIP_TRY(hipMemsetAsync(s_key_in, 0xFF, sort_n * 4, ctx->stream)); // unused tail: sorts behind every item
       hipLaunchKernelGGL(k_slice_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
-                         pl.r_nnz, s_off, s_items, sort_n ? s_key_in : nullptr, rm, ctx->slice_run_min, ctx->slice_run_div);
+                         pl.r_nnz, s_off, s_items, sort_n ? s_key_in : nullptr, rm, ctx->slice_run_min, ctx->slice_run_div, ctx->slice_sorted == 2 ? 1u : 0u);
       if (sort_n) {
         // Items in the order of their first column: the wavefronts that run together then work on
         // the same band of columns, in whatever rows, and so on the same stretch of the (hub) rows
