@@ -556,9 +556,10 @@ __global__ void __launch_bounds__(256)
   uint64_t o = offset[i];
   for (uint32_t c = 0; c < chunks; c += g) {
     const uint32_t nc = min(g, chunks - c);
-    // the sort key: the item's first output column, or (by_cost) what the item costs, the dearest first:
-    // every chunk walks the item's list of A entries and adds a chunk's worth of products
-    if (keys) keys[o] = by_cost ? 0xFFFFFFFEu - (uint32_t)min((uint64_t)0xFFFFFFF0u, (uint64_t)nc * (len_a + SLICE_W)) : tin[(size_t)c * SLICE_W];
+    // the sort key: the item's first output column, or (by_cost, the weight of an A entry in quarters of a
+    // product) what the item costs, the dearest first: every chunk walks the item's list of A entries and
+    // adds a chunk's worth of products
+    if (keys) keys[o] = by_cost ? 0xFFFFFFFEu - (uint32_t)min((uint64_t)0xFFFFFFF0u, (uint64_t)nc * ((len_a * by_cost >> 2) + SLICE_W)) : tin[(size_t)c * SLICE_W];
     items[o++] = SliceItem{row, c, nc};
   }
 }
