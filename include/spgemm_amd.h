@@ -141,13 +141,16 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   symbolic kernel takes the pieces of B's rows per window
  *                                                   from bounds computed once per B (no cursors, independent
  *                                                   loads); 0: it walks every row from a cursor
+ *   big_sym_sorted                                  1 (default): that kernel takes its rows in the order
+ *                                                   of their product bound, the dearest first; 0: row order
  *   slice_blocks                                    workgroups of the big-row numeric kernel (0: fill)
  *   slice_queues                                    1..8 work queues of that kernel (workgroup b starts
  *                                                   on queue b mod queues: 8 = one queue per XCD)
  *   slice_run_min, slice_run_div                    chunks per work item of that kernel: at least
- *                                                   run_min (4..64), one more per run_div A entries
- *   slice_sorted                                    1: its work items are taken in the order of their
- *                                                   first output column instead of row by row
+ *                                                   run_min (default 64), one more per run_div A entries
+ *   slice_sorted                                    its work items are taken 0: row by row; 1: in the order
+ *                                                   of their first output column; 2 (default): the dearest
+ *                                                   first (slice_cost_w: weight of an A entry in the cost)
  *   slice_packed                                    1: it reads B as 12-byte {column, value} records
  *                                                   (built once per B handle)
  *   lane_order_adds                                 1 (default): where the device passed the probe run
