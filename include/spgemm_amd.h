@@ -149,8 +149,10 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *   slice_run_min, slice_run_div                    chunks per work item of that kernel: at least
  *                                                   run_min (default 64), one more per run_div A entries
  *   slice_sorted                                    its work items are taken 0: row by row; 1: in the order
- *                                                   of their first output column; 2 (default): the dearest
- *                                                   first (slice_cost_w: weight of an A entry in the cost)
+ *                                                   of their first output column; 2: the dearest first
+ *                                                   (slice_cost_w: weight of an A entry in the cost);
+ *                                                   3 (default): by the cost's power of two, the dearest
+ *                                                   first, and by first output column inside one
  *   slice_packed                                    1: it reads B as 12-byte {column, value} records
  *                                                   (built once per B handle)
  *   lane_order_adds                                 1 (default): where the device passed the probe run

@@ -559,7 +559,14 @@ __global__ void __launch_bounds__(256)
     // the sort key: the item's first output column, or (by_cost, the weight of an A entry in quarters of a
     // product) what the item costs, the dearest first: every chunk walks the item's list of A entries and
     // adds a chunk's worth of products
-    if (keys) keys[o] = by_cost ? 0xFFFFFFFEu - (uint32_t)min((uint64_t)0xFFFFFFF0u, (uint64_t)nc * ((len_a * by_cost >> 2) + SLICE_W)) : tin[(size_t)c * SLICE_W];
+    if (keys) {
+      const uint64_t cost = (uint64_t)nc * ((len_a * (by_cost & 0xFFFFu) >> 2) + SLICE_W);
+      if (by_cost >> 16) { // by the cost's order of magnitude (a power of two), the dearest first; inside one, by first column
+        const uint32_t mag = 63u - (uint32_t)__clzll((long long)(cost | 1ull)); // 0..63
+        keys[o] = ((63u - mag) << 26) | (tin[(size_t)c * SLICE_W] >> 6);
+      } else
+        keys[o] = by_cost ? 0xFFFFFFFEu - (uint32_t)min((uint64_t)0xFFFFFFF0u, cost) : tin[(size_t)c * SLICE_W];
+    }
     items[o++] = SliceItem{row, c, nc};
   }
 }

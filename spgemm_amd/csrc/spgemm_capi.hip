@@ -120,7 +120,7 @@ struct spgemm_ctx {
                                  // count-only symbolic kernel their columns from a padded array of its own
   uint32_t slice_run_min = 64;   // chunks in a run of the slice kernel: at least this many (4..65536) ...
   uint32_t slice_run_div = 64;   // ... and one more per this many entries of the A row
-  uint32_t slice_sorted = 2;     // the slice kernel takes its items 0: in row order; 1: in the order of their first column; 2: the dearest first
+  uint32_t slice_sorted = 3;     // the slice kernel takes its items 0: in row order; 1: in the order of their first column; 2: the dearest first; 3: by the cost's power of two, then by first column
   uint32_t slice_cost_w = 4;     // slice_sorted = 2: weight of an A entry of the row against a product, in quarters
   uint32_t slice_packed = 0;     // 1: the slice kernel reads B as 12-byte {column, value} records
   uint32_t slice_sampled = 1;    // 1: its searches inside rows of B go over a 1-in-32 sample of B's columns first
@@ -839,7 +839,7 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
     if (value < 1 || value > 65536) return fail(SPGEMM_ERR_INVALID, "slice_run_div must be 1..65536");
     ctx->slice_run_div = (uint32_t)value;
   } else if (n == "slice_sorted") {
-    if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(SPGEMM_ERR_INVALID, "slice_sorted must be 0..3");
     ctx->slice_sorted = (uint32_t)value;
   } else if (n == "slice_cost_w") {
     if (value < 1 || value > 1024) return fail(SPGEMM_ERR_INVALID, "slice_cost_w must be 1..1024");
@@ -1667,7 +1667,7 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       TRY(launch_scan(ctx, s_count, cnt, s_off, partial));
       if (sort_n) HIP_TRY(hipMemsetAsync(s_key_in, 0xFF, sort_n * 4, ctx->stream)); // unused tail: sorts behind every item
       hipLaunchKernelGGL(k_slice_fill, dim3(div_up_u64(cnt, 256)), dim3(256), 0, ctx->stream, rows_bin, cnt, A->d_ptr,
-                         pl.r_nnz, s_off, s_items, sort_n ? s_key_in : nullptr, rm, ctx->slice_run_min, ctx->slice_run_div, ctx->slice_sorted == 2 ? ctx->slice_cost_w : 0u);
+                         pl.r_nnz, s_off, s_items, sort_n ? s_key_in : nullptr, rm, ctx->slice_run_min, ctx->slice_run_div, ctx->slice_sorted >= 2 ? ctx->slice_cost_w | (ctx->slice_sorted == 3 ? 1u << 16 : 0u) : 0u);
       if (sort_n) {
         // Items in the order of their first column: the wavefronts that run together then work on
         // the same band of columns, in whatever rows, and so on the same stretch of the (hub) rows

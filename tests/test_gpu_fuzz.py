@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEFAULTS = {"window_max_span": 65536, "window_ratio": 128, "hash_max_nprod": 8192, "big_win_words": 32768,
             "slice_blocks": 0, "hash_num_slice": 1024, "row_groups": 1, "flat_walk": 1, "big_rows": 1,
             "g_thresh2": 24, "lane_order_adds": 1, "slice_queues": 1, "slice_packed": 0, "short_packed": 2, "grp_compact": 2, "short_key32": 1, "analyze_lanes": 0, "walk_tail": 2, "grp_runs": 1, "big_sym_bounds": 1, "sym_rpw": 8, "grp_rpw": 8, "slice_sampled": 1, "rpw_fill": 16,
-            "slice_sorted": 2, "big_sym_sorted": 1, "slice_run_min": 64, "short_rpw": 16, "short_num_rpw": 8}
+            "slice_sorted": 3, "big_sym_sorted": 1, "slice_run_min": 64, "short_rpw": 16, "short_num_rpw": 8}
 
 
 def to_o(h):
@@ -87,7 +87,7 @@ def make_case(seed):
     opts["grp_rpw"] = int(rng.choice([1, 2, 8]))
     opts["slice_sampled"] = int(rng.integers(0, 3) != 0)
     opts["rpw_fill"] = int(rng.choice([0, 0, 16]))  # 0: several rows / groups per wavefront on these small inputs too
-    opts["slice_sorted"] = int(rng.integers(0, 3))   # row order, by first column, the dearest first
+    opts["slice_sorted"] = int(rng.integers(0, 4))   # row order, by first column, the dearest first, by magnitude then column
     opts["big_sym_sorted"] = int(rng.integers(0, 2))
     opts["slice_run_min"] = int(rng.choice([4, 64]))
     opts["short_rpw"] = int(rng.choice([2, 16]))
