@@ -1642,7 +1642,9 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
       const size_t b_items = align_up(max_items * sizeof(SliceItem), 256);
       const size_t b_lists = align_up((size_t)blocks * list_cap * SLICE_ENTRY_BYTES, 256);
       // sorted items: a run has at least four chunks, so a row of n outputs has at most n / (4 SLICE_W) + 2 items
-      const size_t sort_n = ctx->slice_sorted ? (size_t)(nnz_structural / (4ull * SLICE_W)) + 2 * (size_t)cnt : 0;
+      // (and never more than max_items, which is what the item arrays hold: with many rows of few chunks
+      // the first bound is the larger one)
+      const size_t sort_n = ctx->slice_sorted ? (size_t)std::min<uint64_t>(max_items, nnz_structural / (4ull * SLICE_W) + 2 * (uint64_t)cnt) : 0;
       const size_t b_keys = align_up(sort_n * 4, 256);
       size_t b_sort_tmp = 0;
       if (sort_n) {

@@ -483,6 +483,27 @@ def test_big_rows_slices_and_windows(ctx, win_words):
         ctx.set_option("big_win_words", 32768)
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_slice_items_sorted_many_rows_of_one_chunk(order):
+    """Thousands of rows of about a hundred outputs in the big-row numeric kernel (hash_num_slice = 64), one
+    item each, the items sorted before the kernel takes them: more items than a quarter of the chunks plus
+    two per row would hold when rows have FEWER than four chunks - the count the sort once ran over.  A fresh
+    context per run: the first multiply writes into new memory, where a lost item shows."""
+    A = hostcsr.erdos_renyi(3000, 10, seed=31)
+    for _ in range(3):
+        c = capi.Context(0)
+        try:
+            c.set_option("window_max_span", 0)
+            c.set_option("short_max_nprod", 0)
+            c.set_option("hash_num_slice", 64)
+            c.set_option("slice_sorted", order)
+            c.set_option("profile_launches", 1)
+            check(c, A, A)
+            assert any(l["phase"] == "numeric" and l["path"] == "big_rows" and l["rows"] > 2000 for l in c.launches())
+        finally:
+            c.close()
+
+
 def test_big_rows_few_workgroups(ctx):
     """The slice kernel hands out items through a counter: one workgroup must drain them all."""
     A = _big_row_matrix(10)
