@@ -155,6 +155,9 @@ int spgemm_synchronize(spgemm_ctx *ctx);
  *                                                   first, and by first output column inside one
  *   slice_packed                                    1: it reads B as 12-byte {column, value} records
  *                                                   (built once per B handle)
+ *   poison_output                                   1: C's column and value arrays are filled with 0xFF
+ *                                                   bytes before the numeric pass, so that an entry no
+ *                                                   kernel writes shows (a test aid; default 0)
  *   lane_order_adds                                 1 (default): where the device passed the probe run
  *                                                   by spgemm_create (one LDS fp64 add applies lanes
  *                                                   that share an address in lane order), the flat

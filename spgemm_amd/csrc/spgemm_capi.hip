@@ -129,6 +129,7 @@ struct spgemm_ctx {
   uint32_t short_rpw = 16;       // most rows one wavefront of the short-row kernels takes in a row
   uint32_t short_num_rpw = 8;    // ... of the numeric one (its wavefronts take rows a launch-wide stride apart)
   uint32_t big_sym_bounds = 1;   // big-row symbolic kernel with precomputed window bounds of B's rows (0: cursor walk)
+  uint32_t poison_output = 0;    // 1: the arrays of C are filled with 0xFF bytes before the numeric pass (tests: a skipped entry shows)
   uint32_t big_sym_sorted = 1;   // ... takes its rows the dearest first (0: in row order)
   uint32_t grp_runs = 1;         // window kernels walk runs of B rows with one column list as one (0: row by row)
   uint32_t rpw_fill = 16;        // ... but no more than leave this many wavefronts of work per wavefront slot of the device (0: no such limit)
@@ -811,6 +812,8 @@ extern "C" int spgemm_set_option(spgemm_ctx *ctx, const char *name, int64_t valu
   } else if (n == "walk_tail") {
     if (value < 0 || value > 2) return fail(SPGEMM_ERR_INVALID, "walk_tail must be 0, 1 or 2");
     ctx->walk_tail = (uint32_t)value;
+  } else if (n == "poison_output") {
+    ctx->poison_output = value != 0;
   } else if (n == "big_sym_sorted") {
     if (value > 1) return fail(SPGEMM_ERR_INVALID, "big_sym_sorted must be 0 or 1");
     ctx->big_sym_sorted = (uint32_t)value;
@@ -1533,6 +1536,10 @@ static int run_numeric(spgemm_ctx *ctx, const spgemm_mat *A, const spgemm_mat *B
   const uint64_t list_cap = slices ? std::max<uint32_t>(pl.max_len_big, 64) : 0;
   uint64_t boff[NUM_NBINS + 1];
   memcpy(boff, pl.num_boff, sizeof(boff));
+  if (ctx->poison_output) { // a test aid: an entry of C that no kernel writes then shows (column 2^32 - 1, value NaN)
+    HIP_TRY(hipMemsetAsync(d_col, 0xFF, nnz_structural * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_val, 0xFF, nnz_structural * 8, ctx->stream));
+  }
   HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
 
   Csr cA{A->d_ptr, A->d_col, A->d_val}, cB{B->d_ptr, B->d_col, B->d_val};
