@@ -114,12 +114,25 @@ def test_random_structure_and_options(seed):
             ctx.set_option(name, value)
         dA = ctx.from_host(A.rows, A.cols, A.row_ptr, A.col_idx, A.val)
         dB = ctx.from_host(B.rows, B.cols, B.row_ptr, B.col_idx, B.val)
-        for _ in range(2):  # the second multiply reuses the context's scratch
+        for it in range(2):  # the second multiply reuses the context's scratch
             dC = ctx.multiply(dA, dB)
             rp, ci, v = dC.to_host()
             dC.free()
             E = orc.spgemm(to_o(A), to_o(B))
-            orc.assert_same(orc.OCsr(A.rows, B.cols, rp, ci, v), E, rtol=0.0)
+            try:
+                orc.assert_same(orc.OCsr(A.rows, B.cols, rp, ci, v), E, rtol=0.0)
+            except AssertionError as err:  # say where: which multiply, how many entries, which rows, unwritten (poisoned) ones
+                detail = f"multiply {it}: nnz {len(ci)} (oracle {E.nnz})"
+                if len(ci) == E.nnz and np.array_equal(rp, E.row_ptr):
+                    Ec = E.canonical()
+                    bad = np.flatnonzero((v != Ec.val) | (ci != Ec.col_idx))
+                    rows_of = np.searchsorted(rp, bad, side="right") - 1
+                    detail += (f"; {len(bad)} entries differ in rows {sorted(set(rows_of.tolist()))[:8]} (lengths "
+                               f"{[int(rp[r + 1] - rp[r]) for r in sorted(set(rows_of.tolist()))[:8]]}, A rows "
+                               f"{[int(A.row_ptr[r + 1] - A.row_ptr[r]) for r in sorted(set(rows_of.tolist()))[:8]]}), at "
+                               f"{[int(b - rp[r]) for b, r in zip(bad[:8], rows_of[:8])]}; NaN values {int(np.isnan(v).sum())}, "
+                               f"poisoned columns {int((ci == 0xFFFFFFFF).sum())}; got {v[bad[:4]].tolist()} want {Ec.val[bad[:4]].tolist()}")
+                raise AssertionError(f"{err} [{detail}]") from err
         dA.free()
         dB.free()
     finally:
